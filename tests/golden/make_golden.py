@@ -1,0 +1,384 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures in this directory from the imported reference.
+
+Run ONLY where /root/reference exists (the build container):
+
+    python tests/golden/make_golden.py
+
+It (1) imports the reference modules with a stub ``xarray`` from a scratch working
+directory (the reference opens a log file in its CWD at import time), (2) asserts
+that the CPU oracle in ``oracle/`` agrees with the reference on every case, and
+(3) freezes the reference's outputs as small ``.npz`` files next to this script.
+The fixtures hold data only: seeds, shapes, expected numbers.  Weights and inputs
+are regenerated from seeds by ``oracle.weights`` wherever the fixtures are used.
+"""
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+sys.dont_write_bytecode = True
+
+from oracle import loss_oracle, swin_oracle, tile_oracle, unet_oracle  # noqa: E402
+from oracle import weights as W  # noqa: E402
+
+
+def import_reference():
+    import importlib.machinery
+    xr = types.ModuleType("xarray")
+    xr.__spec__ = importlib.machinery.ModuleSpec("xarray", None)
+    xr.Dataset = type("Dataset", (), {})
+    xr.DataArray = type("DataArray", (), {})
+    xr.open_dataset = lambda *a, **k: None
+    xr.open_dataarray = lambda *a, **k: None
+    sys.modules["xarray"] = xr
+    os.chdir(tempfile.mkdtemp(prefix="refscratch_"))
+    sys.path.insert(0, REF)
+    import enhanced_training_multi_loss as etml
+    import large_area_predictor as lap
+    import swin_unet_model as swin
+    import training as tr
+    return tr, etml, swin, lap
+
+
+def close(a, b, tol, what):
+    a = torch.as_tensor(a).double()
+    b = torch.as_tensor(b).double()
+    err = (a - b).norm() / max(b.norm().item(), 1e-30)
+    assert err <= tol, f"oracle != reference for {what}: rel {err:.3e}"
+    return float(err)
+
+
+def sub(t, n=4096):
+    """Deterministic subsample of a tensor (flat stride)."""
+    f = t.detach().reshape(-1)
+    step = max(1, f.numel() // n)
+    return f[::step][:n].numpy().copy()
+
+
+UNET_CASES = [  # name, in_ch, features, batch, H, W
+    ("c1", 1, 48, 4, 128, 128),      # BASELINE config 1
+    ("small", 4, 8, 2, 32, 32),
+    ("ragged", 4, 8, 2, 40, 24),
+    ("odd", 4, 16, 1, 50, 36),       # 50->25->12->6->3: resize is not an exact 2x
+    ("f48", 4, 48, 1, 64, 64),
+]
+
+
+def gen_unet(tr):
+    out = {}
+    for name, cin, f, B, H, Wd in UNET_CASES:
+        sd = W.fill_state_dict(W.unet_template(cin, 1, f), seed=42)
+        x, y, w = W.synthetic_batch(B, cin, H, Wd, seed=42)
+        ref = tr.OptimizedUNet(cin, 1, f)
+        ref.load_state_dict(sd)
+        # eval forward
+        ref.eval()
+        with torch.no_grad():
+            r_eval = ref(x)
+        o_eval, _ = unet_oracle.unet_forward(sd, x, False)
+        close(o_eval, r_eval, 1e-6, f"unet {name} eval")
+        # train forward+backward, dropout p=0, MSE loss against y
+        ref.train()
+        for m in ref.modules():
+            if isinstance(m, torch.nn.Dropout2d):
+                m.p = 0.0
+        ref.zero_grad()
+        xr_ = x.clone().requires_grad_(True)
+        r_out = ref(xr_)
+        r_loss = ((r_out - y) ** 2).mean()
+        r_loss.backward()
+        o_out, o_loss, o_g, o_stats = unet_oracle.unet_fwd_bwd(sd, x, lambda o: ((o - y) ** 2).mean())
+        close(o_out, r_out, 1e-6, f"unet {name} train out")
+        close(o_loss, r_loss, 1e-6, f"unet {name} loss")
+        rsd = ref.state_dict()
+        for k, p in ref.named_parameters():
+            close(o_g[k], p.grad, 2e-5, f"unet {name} grad {k}")
+        close(o_g["__input__"], xr_.grad, 2e-5, f"unet {name} grad input")
+        for k, v in o_stats.items():
+            close(v, rsd[k], 1e-6, f"unet {name} stat {k}")
+        names = [k for k, _ in ref.named_parameters()]
+        out[f"{name}.eval_out"] = sub(r_eval, 16384)
+        out[f"{name}.train_out"] = sub(r_out, 16384)
+        out[f"{name}.loss"] = np.float64(r_loss.item())
+        out[f"{name}.grad_norms"] = np.array([p.grad.double().norm().item() for _, p in ref.named_parameters()])
+        out[f"{name}.grad_heads"] = np.concatenate([sub(p.grad, 16) for _, p in ref.named_parameters()])
+        out[f"{name}.grad_input"] = sub(xr_.grad, 4096)
+        out[f"{name}.param_names"] = np.array(names)
+        stat_names = sorted(o_stats)
+        out[f"{name}.stat_names"] = np.array(stat_names)
+        out[f"{name}.stats"] = np.concatenate([sub(rsd[k], 8) for k in stat_names])
+    # seeded dropout: the oracle draws masks exactly as nn.Dropout2d does
+    name, cin, f, B, H, Wd = UNET_CASES[1]
+    sd = W.fill_state_dict(W.unet_template(cin, 1, f), seed=42)
+    x, y, w = W.synthetic_batch(B, cin, H, Wd, seed=42)
+    ref = tr.OptimizedUNet(cin, 1, f)
+    ref.load_state_dict(sd)
+    ref.train()
+    torch.manual_seed(1234)
+    r = ref(x)
+    torch.manual_seed(1234)
+    masks = unet_oracle.draw_dropout_masks(B, f)
+    o, _ = unet_oracle.unet_forward(sd, x, True, masks)
+    close(o, r, 1e-6, "unet seeded dropout")
+    out["small.dropout_seed1234_out"] = sub(r, 16384)
+    np.savez_compressed(os.path.join(HERE, "unet.npz"), **out)
+    print("unet.npz", len(out), "entries")
+
+
+LOSS_CFGS = {
+    "baseline": dict(comb="baseline", use_tid=False, grad_w=0.0, spec_w=0.0),
+    "weighted_mse": dict(comb="weighted_mse", grad_w=0.0, spec_w=0.0),
+    "weighted_mse_grad": dict(comb="weighted_mse_grad", grad_w=0.3, spec_w=0.0),
+    "weighted_mse_fft": dict(comb="weighted_mse_fft", grad_w=0.0, spec_w=0.2),
+    "all": dict(comb="all", grad_w=0.3, spec_w=0.2),
+    "all_aggr": dict(comb="all", grad_w=0.5, spec_w=0.3, scale=1.2, factor=2.5),
+    "all_s05_f15": dict(comb="all", grad_w=0.3, spec_w=0.2, scale=0.5, factor=1.5),
+    "all_s2_f3": dict(comb="all", grad_w=0.3, spec_w=0.2, scale=2.0, factor=3.0),
+    "mae_all": dict(comb="all", grad_w=0.3, spec_w=0.2, pixel_type="mae"),
+    "diff_grad": dict(comb="weighted_mse_grad", grad_w=0.3, spec_w=0.0, method="diff"),
+}
+
+
+def gen_loss(etml):
+    out = {}
+    shapes = [(3, 32, 32), (2, 24, 40), (2, 128, 128)]
+    for si, (B, H, Wd) in enumerate(shapes):
+        _, y, w = W.synthetic_batch(B, 1, H, Wd, seed=7 + si)
+        p = W.synthetic_batch(B, 1, H, Wd, seed=100 + si)[1] * 0.7 + 0.3 * y
+        for wname, wt in (("none", None), ("rand", w), ("zero", torch.zeros_like(w))):
+            for cname, kw in LOSS_CFGS.items():
+                cfg = loss_oracle.preset(**kw)
+                ref = etml.MultiLossFunction(cfg)
+                pr = p.clone().requires_grad_(True)
+                r_total, r_parts = ref(pr, y, wt)
+                r_total.backward()
+                po = p.clone().requires_grad_(True)
+                o_total, o_parts = loss_oracle.multi_loss(cfg, po, y, wt)
+                o_total.backward()
+                close(o_total, r_total, 1e-6, f"loss {cname}/{wname}/{si}")
+                for k in ("pixel", "gradient", "spectral", "total"):
+                    assert abs(o_parts[k] - r_parts[k]) <= 1e-6 * max(1.0, abs(r_parts[k])), (cname, k)
+                close(po.grad, pr.grad, 1e-5, f"loss grad {cname}/{wname}/{si}")
+                key = f"s{si}.{wname}.{cname}"
+                out[key + ".parts"] = np.array([r_parts[k] for k in ("pixel", "gradient", "spectral", "total")])
+                out[key + ".grad"] = sub(pr.grad, 2048)
+    # frequency weight known answers (DC-heavy quirk)
+    fw = loss_oracle.spectral_weight(128, 128, 2.0)
+    assert abs(fw[0, 0].item() - 2.0) < 1e-6 and abs(fw[64, 64].item() - 1.0) < 1e-6
+    out["fw_128_2.0"] = fw.numpy()
+    np.savez_compressed(os.path.join(HERE, "loss.npz"), **out)
+    print("loss.npz", len(out), "entries")
+
+
+class _Var:
+    def __init__(self, a):
+        self.a = a
+
+    def isel(self, lat, lon):
+        return types.SimpleNamespace(values=self.a[lat, lon])
+
+
+class _DS(dict):
+    """Duck-typed stand-in for the xarray.Dataset predict_large_area reads."""
+    def __init__(self, arrays):
+        super().__init__({k: _Var(v) for k, v in arrays.items()})
+        any_a = next(iter(arrays.values()))
+        self.lat = np.arange(any_a.shape[0])
+        self.lon = np.arange(any_a.shape[1])
+
+
+class _ToyNet(torch.nn.Module):
+    """Cheap deterministic stand-in model: a fixed 3x3 conv over the 4 channels."""
+    def __init__(self):
+        super().__init__()
+        g = np.random.Generator(np.random.PCG64(5))
+        self.w = torch.from_numpy(g.normal(0, 0.3, (1, 4, 3, 3)).astype(np.float32))
+
+    def forward(self, x):
+        return torch.tanh(torch.nn.functional.conv2d(x, self.w, padding=1))
+
+
+def toy_features(lat, lon, seed, nan_block=None, nan_speckle=0.0):
+    g = np.random.Generator(np.random.PCG64(seed))
+    arrays = {}
+    for v in tile_oracle.FEATURE_VARS:
+        a = g.normal(0, 1, (lat, lon)).astype(np.float32)
+        if nan_speckle:
+            a[g.random((lat, lon)) < nan_speckle] = np.nan
+        arrays[v] = a
+    if nan_block is not None:
+        i0, i1, j0, j1 = nan_block
+        arrays["DOV_NS"][i0:i1, j0:j1] = np.nan
+    return arrays
+
+
+TILE_CASES = [  # name, lat, lon, P, S, nan_block, speckle
+    ("g200x168_p64_s32", 200, 168, 64, 32, (0, 70, 90, 168), 0.01),
+    ("g160_p32_s2", 160, 160, 32, 2, None, 0.0),
+    ("g512_p128_s64", 512, 512, 128, 64, (128, 300, 0, 200), 0.0),
+    ("g300x260_p128_s8", 300, 260, 128, 8, None, 0.002),
+]
+
+
+def gen_tile(lap):
+    out = {}
+    for P in (8, 64, 128, 256):
+        cfg = type("C", (), {"OUTPUT_DIR": tempfile.mkdtemp(), "PATCH_SIZE": P, "STRIDE": P // 2, "BATCH_SIZE": 16})
+        k_ref = lap.LargeAreaPredictor(cfg).create_gaussian_weight_kernel(P)
+        k_or = tile_oracle.gaussian_weight_kernel(P)
+        assert np.array_equal(k_ref, k_or), f"gaussian kernel P={P} not bit-exact"
+        out[f"kernel_{P}"] = k_ref
+    net = _ToyNet().eval()
+    lap.device = torch.device("cpu")
+    for name, lat, lon, P, S, nb, sp in TILE_CASES:
+        feats = toy_features(lat, lon, 11, nb, sp)
+        cfg = type("C", (), {"OUTPUT_DIR": tempfile.mkdtemp(), "PATCH_SIZE": P, "STRIDE": S, "BATCH_SIZE": 16})
+        pred = lap.LargeAreaPredictor(cfg)
+        r = pred.predict_large_area(net, _DS({k: v.copy() for k, v in feats.items()}))
+        o = tile_oracle.predict_large_area(lambda b: net(torch.from_numpy(b)).numpy(),
+                                           {k: v.copy() for k, v in feats.items()}, P, S, 16)
+        assert np.array_equal(r, o), f"tiled predict {name} not bit-exact"
+        pos, _ = tile_oracle.collect_tiles(feats, P, S)
+        out[name + ".pos"] = np.array(pos, dtype=np.int32)
+        out[name + ".pred"] = r.astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "tile.npz"), **out)
+    print("tile.npz", len(out), "entries")
+
+
+SWIN_CASES = [("s256", 1, 256, 256), ("s64", 2, 64, 64), ("s128x64", 1, 128, 64)]
+
+
+def gen_swin(swin):
+    out = {}
+    cfg = dict(swin_oracle.DEFAULT_CONFIG)
+    ref = swin.SwinUNet(dict(cfg, use_checkpoint=False))
+    template = {k: v for k, v in ref.state_dict().items()}
+    assert list(template) == list(swin_oracle.swin_template(cfg)), "state_dict key order differs"
+    for k, v in swin_oracle.swin_template(cfg).items():
+        assert tuple(v.shape) == tuple(template[k].shape), k
+        if k.endswith("relative_position_index"):
+            assert torch.equal(v, template[k])
+    sd = W.fill_state_dict(template, seed=42)
+    ref.load_state_dict(sd)
+    for name, B, H, Wd in SWIN_CASES:
+        x, y, w = W.synthetic_batch(B, 4, H, Wd, seed=42)
+        ref.eval()
+        with torch.no_grad():
+            r_eval = ref(x)
+        o_eval, _ = swin_oracle.swin_unet_forward(sd, x, cfg, False)
+        close(o_eval, r_eval, 1e-5, f"swin {name} eval")
+        out[f"{name}.eval_out"] = sub(r_eval, 16384)
+        if name == "s256":
+            continue
+        # train mode, DropPath rate forced to 0, MSE against the half-resolution label.
+        # Done in float64: with batch statistics over a handful of elements the fp32
+        # gradients of either implementation carry ~5e-3 of rounding noise, so the
+        # frozen numbers are the float64 ones (oracle == reference to 1e-12 there).
+        ref64 = swin.SwinUNet(dict(cfg, use_checkpoint=False)).double()
+        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+        ref64.load_state_dict(sd64)
+        ref64.train()
+        for m in ref64.modules():
+            if isinstance(m, swin.DropPath):
+                m.drop_prob = 0.0
+        x64, y64 = x.double(), y.double()
+        xr_ = x64.clone().requires_grad_(True)
+        r_out = ref64(xr_)
+        tgt = torch.nn.functional.avg_pool2d(y64, 2)
+        r_loss = ((r_out - tgt) ** 2).mean()
+        r_loss.backward()
+        params = {k: v.clone().requires_grad_(True) for k, v in sd64.items()
+                  if v.is_floating_point() and "running_" not in k}
+        full = dict(sd64)
+        full.update(params)
+        xo = x64.clone().requires_grad_(True)
+        o_out, o_stats = swin_oracle.swin_unet_forward(full, xo, cfg, True, None)
+        o_loss = ((o_out - tgt) ** 2).mean()
+        o_loss.backward()
+        close(o_out, r_out, 1e-12, f"swin {name} train out")
+        rsd = ref64.state_dict()
+        for k, p in ref64.named_parameters():
+            if k == "final_conv.0.bias":      # a bias in front of BatchNorm: gradient is exactly 0
+                assert p.grad.abs().max() < 1e-12 and params[k].grad.abs().max() < 1e-12
+                continue
+            close(params[k].grad, p.grad, 1e-9, f"swin {name} grad {k}")
+        close(xo.grad, xr_.grad, 1e-9, f"swin {name} grad input")
+        for k, v in o_stats.items():
+            close(v, rsd[k], 1e-12, f"swin {name} stat {k}")
+        out[f"{name}.train_out"] = sub(r_out, 16384)
+        out[f"{name}.loss"] = np.float64(r_loss.item())
+        out[f"{name}.grad_norms"] = np.array([p.grad.norm().item() for _, p in ref64.named_parameters()])
+        out[f"{name}.param_names"] = np.array([k for k, _ in ref64.named_parameters()])
+        out[f"{name}.grad_input"] = sub(xr_.grad, 4096)
+        stat_names = sorted(o_stats)
+        out[f"{name}.stat_names"] = np.array(stat_names)
+        out[f"{name}.stats"] = np.concatenate([sub(rsd[k], 8) for k in stat_names])
+    # seeded DropPath: oracle draws as drop_path() does
+    name, B, H, Wd = SWIN_CASES[1]
+    x, _, _ = W.synthetic_batch(B, 4, H, Wd, seed=42)
+    ref.load_state_dict(sd)
+    ref.train()
+    torch.manual_seed(99)
+    r = ref(x)
+    torch.manual_seed(99)
+    dp = swin_oracle.draw_drop_path(cfg, B)
+    o, _ = swin_oracle.swin_unet_forward(sd, x, cfg, True, dp)
+    close(o, r, 1e-5, "swin seeded droppath")
+    out["s64.droppath_seed99_out"] = sub(r, 16384)
+    # per-stage shift masks at 256 px input (64,32,16,8 tokens a side) and a pad case
+    for hw in (64, 32, 16, 8, 4):
+        out[f"mask_{hw}"] = swin_oracle.shift_mask(hw, hw, 8).numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "swin.npz"), **out)
+    print("swin.npz", len(out), "entries")
+
+
+def gen_step(etml):
+    """One optimiser step as the trainer does it (enhanced_training_multi_loss.py:819-829)."""
+    cin, f, B, H, Wd = 4, 8, 2, 32, 32
+    sd = W.fill_state_dict(W.unet_template(cin, 1, f), seed=42)
+    x, y, w = W.synthetic_batch(B, cin, H, Wd, seed=42)
+    ref = etml.OptimizedUNet(cin, 1, f)
+    ref.load_state_dict(sd)
+    ref.train()
+    for m in ref.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0
+    crit = etml.MultiLossFunction(loss_oracle.preset("all"))
+    opt = torch.optim.AdamW(ref.parameters(), lr=5e-5, weight_decay=5e-5, betas=(0.9, 0.999))
+    loss, parts = crit(ref(x), y, w)
+    opt.zero_grad()
+    loss.backward()
+    gn = torch.nn.utils.clip_grad_norm_(ref.parameters(), max_norm=1.0)
+    opt.step()
+    out = {"parts": np.array([parts[k] for k in ("pixel", "gradient", "spectral", "total")]),
+           "grad_norm": np.float64(gn.item()),
+           "param_names": np.array([k for k, _ in ref.named_parameters()]),
+           "param_delta_norms": np.array([(p.detach() - sd[k]).double().norm().item()
+                                          for k, p in ref.named_parameters()]),
+           "param_heads": np.concatenate([sub(p, 8) for _, p in ref.named_parameters()])}
+    np.savez_compressed(os.path.join(HERE, "step.npz"), **out)
+    print("step.npz", len(out), "entries")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    tr, etml, swin, lap = import_reference()
+    which = sys.argv[1:] or ["unet", "loss", "tile", "swin", "step"]
+    if "unet" in which:
+        gen_unet(tr)
+    if "loss" in which:
+        gen_loss(etml)
+    if "tile" in which:
+        gen_tile(lap)
+    if "swin" in which:
+        gen_swin(swin)
+    if "step" in which:
+        gen_step(etml)

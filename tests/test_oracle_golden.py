@@ -1,0 +1,160 @@
+"""CPU tests: the oracle reproduces the fixtures frozen from the imported reference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import loss_oracle, swin_oracle, tile_oracle, unet_oracle
+from oracle import weights as W
+
+
+def sub(t, n=4096):
+    f = torch.as_tensor(t).detach().reshape(-1)
+    step = max(1, f.numel() // n)
+    return f[::step][:n].numpy()
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+UNET_CASES = {"c1": (1, 48, 4, 128, 128), "small": (4, 8, 2, 32, 32), "ragged": (4, 8, 2, 40, 24),
+              "odd": (4, 16, 1, 50, 36), "f48": (4, 48, 1, 64, 64)}
+
+
+@pytest.mark.parametrize("name", ["small", "ragged", "odd", "f48", "c1"])
+def test_unet_oracle_matches_golden(golden, name):
+    g = golden("unet")
+    cin, f, B, H, Wd = UNET_CASES[name]
+    sd = W.fill_state_dict(W.unet_template(cin, 1, f), seed=42)
+    x, y, _ = W.synthetic_batch(B, cin, H, Wd, seed=42)
+    o_eval, _ = unet_oracle.unet_forward(sd, x, False)
+    assert rel(sub(o_eval, 16384), g[f"{name}.eval_out"]) < 1e-6
+    out, loss, grads, stats = unet_oracle.unet_fwd_bwd(sd, x, lambda o: ((o - y) ** 2).mean())
+    assert rel(sub(out, 16384), g[f"{name}.train_out"]) < 1e-6
+    assert abs(loss.item() - g[f"{name}.loss"]) < 1e-6 * max(1, abs(g[f"{name}.loss"]))
+    names = [str(s) for s in g[f"{name}.param_names"]]
+    norms = np.array([grads[k].double().norm().item() for k in names])
+    assert rel(norms, g[f"{name}.grad_norms"]) < 1e-4
+    assert rel(sub(grads["__input__"], 4096), g[f"{name}.grad_input"]) < 1e-4
+    st = np.concatenate([sub(stats[str(k)], 8) for k in g[f"{name}.stat_names"]])
+    assert rel(st, g[f"{name}.stats"]) < 1e-6
+
+
+def test_unet_param_count_known_answers():
+    # reference training log :19 and the 1-channel variant
+    n4 = sum(v.numel() for k, v in W.unet_template(4, 1, 48).items()
+             if v.is_floating_point() and "running_" not in k)
+    n1 = sum(v.numel() for k, v in W.unet_template(1, 1, 48).items()
+             if v.is_floating_point() and "running_" not in k)
+    assert n4 == 17_656_945 and n1 == 17_655_649
+    assert len(W.unet_template()) == 110
+
+
+def test_unet_seeded_dropout(golden):
+    g = golden("unet")
+    cin, f, B, H, Wd = UNET_CASES["small"]
+    sd = W.fill_state_dict(W.unet_template(cin, 1, f), seed=42)
+    x, _, _ = W.synthetic_batch(B, cin, H, Wd, seed=42)
+    torch.manual_seed(1234)
+    masks = unet_oracle.draw_dropout_masks(B, f)
+    o, _ = unet_oracle.unet_forward(sd, x, True, masks)
+    assert rel(sub(o, 16384), g["small.dropout_seed1234_out"]) < 1e-6
+
+
+LOSS_CFGS = {
+    "baseline": dict(comb="baseline", use_tid=False, grad_w=0.0, spec_w=0.0),
+    "weighted_mse": dict(comb="weighted_mse", grad_w=0.0, spec_w=0.0),
+    "weighted_mse_grad": dict(comb="weighted_mse_grad", grad_w=0.3, spec_w=0.0),
+    "weighted_mse_fft": dict(comb="weighted_mse_fft", grad_w=0.0, spec_w=0.2),
+    "all": dict(comb="all", grad_w=0.3, spec_w=0.2),
+    "all_aggr": dict(comb="all", grad_w=0.5, spec_w=0.3, scale=1.2, factor=2.5),
+    "all_s05_f15": dict(comb="all", grad_w=0.3, spec_w=0.2, scale=0.5, factor=1.5),
+    "all_s2_f3": dict(comb="all", grad_w=0.3, spec_w=0.2, scale=2.0, factor=3.0),
+    "mae_all": dict(comb="all", grad_w=0.3, spec_w=0.2, pixel_type="mae"),
+    "diff_grad": dict(comb="weighted_mse_grad", grad_w=0.3, spec_w=0.0, method="diff"),
+}
+LOSS_SHAPES = [(3, 32, 32), (2, 24, 40), (2, 128, 128)]
+
+
+def loss_inputs(si):
+    B, H, Wd = LOSS_SHAPES[si]
+    _, y, w = W.synthetic_batch(B, 1, H, Wd, seed=7 + si)
+    p = W.synthetic_batch(B, 1, H, Wd, seed=100 + si)[1] * 0.7 + 0.3 * y
+    return p, y, w
+
+
+@pytest.mark.parametrize("si", [0, 1, 2])
+def test_loss_oracle_matches_golden(golden, si):
+    g = golden("loss")
+    p, y, w = loss_inputs(si)
+    for wname, wt in (("none", None), ("rand", w), ("zero", torch.zeros_like(w))):
+        for cname, kw in LOSS_CFGS.items():
+            cfg = loss_oracle.preset(**kw)
+            po = p.clone().requires_grad_(True)
+            total, parts = loss_oracle.multi_loss(cfg, po, y, wt)
+            total.backward()
+            key = f"s{si}.{wname}.{cname}"
+            got = np.array([parts[k] for k in ("pixel", "gradient", "spectral", "total")])
+            assert np.allclose(got, g[key + ".parts"], rtol=1e-6, atol=1e-9), key
+            assert rel(sub(po.grad, 2048), g[key + ".grad"]) < 1e-5, key
+
+
+def test_spectral_weight_is_dc_heavy(golden):
+    fw = loss_oracle.spectral_weight(128, 128, 2.0)
+    assert np.array_equal(fw.numpy(), golden("loss")["fw_128_2.0"])
+    assert abs(fw[0, 0].item() - 2.0) < 1e-6 and abs(fw[64, 64].item() - 1.0) < 1e-6
+
+
+def test_spectral_without_high_freq_focus_raises():
+    p, y, w = loss_inputs(0)
+    with pytest.raises(NameError):
+        loss_oracle.spectral_loss(p, y, w, focus_high_freq=False)
+
+
+@pytest.mark.parametrize("P", [8, 64, 128, 256])
+def test_gaussian_kernel_bit_exact(golden, P):
+    k = tile_oracle.gaussian_weight_kernel(P)
+    assert k.dtype == np.float32 and np.array_equal(k, golden("tile")[f"kernel_{P}"])
+    if P == 256:   # known answers
+        assert abs(float(k.min()) - 0.018895887) < 1e-9 and abs(float(k.max()) - 0.999938965) < 1e-9
+
+
+def test_tile_count_known_answer():
+    assert len(tile_oracle.tile_starts(8192, 256, 128)) ** 2 == 3969
+
+
+def test_swin_known_answers(golden):
+    tpl = swin_oracle.swin_template()
+    assert len(tpl) == 249
+    n = sum(v.numel() for k, v in tpl.items() if v.is_floating_point() and "running_" not in k)
+    assert n == 37_810_795
+    g = golden("swin")
+    for hw in (64, 32, 16, 8, 4):
+        assert np.array_equal(swin_oracle.shift_mask(hw, hw, 8).numpy(), g[f"mask_{hw}"])
+    # the mask is applied even when the map is one window: 75 % of entries are -100
+    assert abs((g["mask_8"] == -100).mean() - 0.75) < 1e-12
+
+
+@pytest.mark.parametrize("name,B,H,Wd", [("s64", 2, 64, 64), ("s128x64", 1, 128, 64)])
+def test_swin_oracle_matches_golden(golden, name, B, H, Wd):
+    g = golden("swin")
+    cfg = swin_oracle.DEFAULT_CONFIG
+    sd = W.fill_state_dict(swin_oracle.swin_template(cfg), seed=42)
+    x, y, _ = W.synthetic_batch(B, 4, H, Wd, seed=42)
+    o, _ = swin_oracle.swin_unet_forward(sd, x, cfg, False)
+    assert rel(sub(o, 16384), g[f"{name}.eval_out"]) < 1e-5
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    params = {k: v.clone().requires_grad_(True) for k, v in sd64.items()
+              if v.is_floating_point() and "running_" not in k}
+    full = dict(sd64)
+    full.update(params)
+    out, stats = swin_oracle.swin_unet_forward(full, x.double(), cfg, True, None)
+    loss = ((out - torch.nn.functional.avg_pool2d(y.double(), 2)) ** 2).mean()
+    loss.backward()
+    assert abs(loss.item() - g[f"{name}.loss"]) < 1e-9
+    names = [str(s) for s in g[f"{name}.param_names"]]
+    norms = np.array([params[k].grad.norm().item() for k in names])
+    keep = np.array([k != "final_conv.0.bias" for k in names])
+    assert rel(norms[keep], g[f"{name}.grad_norms"][keep]) < 1e-8
