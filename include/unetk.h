@@ -1,0 +1,111 @@
+/* libunetk: C ABI of the MI355X (gfx950) kernels behind the UNet / Swin-UNet hot path.
+ *
+ * The reference project is pure Python on PyTorch and has no FFI layer of its own; the
+ * entry points below are what its nn.Module forwards (and autograd's backwards of them)
+ * dispatch to, one family per ATen op the hot path uses.  Each declaration names the
+ * reference lines whose arithmetic it replaces.
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer unless named host_*; the caller owns all buffers,
+ *    workspaces included (query the *_bytes / *_elems functions).  Nothing here
+ *    allocates, frees or synchronises; kernels are enqueued on `stream`.
+ *  - Activations are NHWC ("channels last") with an explicit channel stride `ld*`
+ *    (elements between consecutive pixels), element type `dtype`.  Parameters,
+ *    statistics, gradients of parameters and model inputs/outputs are fp32; model
+ *    inputs/outputs are NCHW as in the reference.
+ *  - Return value: UNETK_OK or a negative error code; unetk_last_error() returns the
+ *    message of the calling thread's last failure.
+ */
+#ifndef UNETK_H
+#define UNETK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* unetk_stream_t; /* == hipStream_t */
+
+enum { UNETK_OK = 0, UNETK_EINVAL = -1, UNETK_ESHAPE = -2, UNETK_EHIP = -3 };
+enum { UNETK_F32 = 0, UNETK_BF16 = 1 };
+enum { UNETK_ACT_NONE = 0, UNETK_ACT_RELU = 1, UNETK_ACT_GELU = 2 };
+
+const char* unetk_last_error(void);
+int unetk_version(void);
+
+/* ---- convolution as implicit GEMM on MFMA ------------------------------------------
+ * nn.Conv2d(k=3, padding=1) / nn.Conv2d(k=1) / nn.Linear:
+ *   training.py:524,527 (DoubleConv), swin_unet_model.py:506,512,515,608 (decoder),
+ *   swin_unet_model.py:234,236,298,301,383 (Swin linears as 1x1).
+ * Weights are re-packed from the reference [Co][Ci][k][k] fp32 layout into the kernel's
+ * [Co/bn][Ci/kc][tap][bn][kc] layout; transpose=1 packs the data-gradient convolution
+ * (in/out swapped, taps flipped), which is then run with unetk_conv_fwd as well. */
+int unetk_conv_pick_bn(int Co);
+int64_t unetk_conv_packed_elems(int Co, int Ci, int ks, int bn, int dtype);
+int unetk_conv_pack_weight(const float* w, void* packed, int Co, int Ci, int ks, int bn, int dtype,
+                           int transpose, unetk_stream_t stream);
+int unetk_conv_num_tiles(int B, int H, int W, int ks);
+/* out = act((conv(in, w)) * ep_scale + ep_shift) [* resid_keep[b] + resid].
+ * stats (nullable): [unetk_conv_num_tiles][2][Co] per-tile sum / sum of squares of the raw
+ * convolution output (fp32 accumulators), the BatchNorm batch statistics of
+ * training.py:525,528 before their deterministic reduction by unetk_bn_finalize. */
+int unetk_conv_fwd(const void* in, int ldin, const void* wpacked, void* out, int ldout, int B, int H,
+                   int W, int Ci, int Co, int ks, int bn, int dtype, float* stats,
+                   const float* ep_scale, const float* ep_shift, int act, const void* resid, int ldres,
+                   const float* resid_keep, unetk_stream_t stream);
+/* dw[Co][Ci][k][k] (+)= sum_pixels dy (x) shifted in   (autograd of the convolutions above) */
+int64_t unetk_conv_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Co, int ks, int dtype);
+int unetk_conv_wgrad(const void* in, int ldin, const void* dy, int lddy, float* dw, int B, int H, int W,
+                     int Ci, int Co, int ks, int dtype, void* workspace, int64_t workspace_bytes,
+                     int accumulate, unetk_stream_t stream);
+
+/* ---- layout ------------------------------------------------------------------------ */
+int unetk_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int ld, int dtype,
+                       unetk_stream_t stream);
+int unetk_nhwc_to_nchw(const void* src, int ld, float* dst, int B, int C, int H, int W, int dtype,
+                       unetk_stream_t stream);
+
+/* ---- BatchNorm2d + ReLU + Dropout2d mask + MaxPool2d(2,2) ---------------------------
+ * training.py:525-530 and :464-473; swin_unet_model.py:513-517, 609-610. */
+int unetk_bn_finalize(const float* partials, int nparts, int C, int64_t count, const float* gamma,
+                      const float* beta, float eps, float momentum, float* running_mean,
+                      float* running_var, float* mean, float* invstd, float* scale, float* shift,
+                      unetk_stream_t stream);
+int unetk_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, const float* conv_bias, float* scale,
+                       float* shift, int C, unetk_stream_t stream);
+/* a = relu(y*scale+shift) * keep[b][c]; pooled (nullable) = 2x2 max of a.
+ * scale/shift null = identity, a null = only the pooled output is written (plain MaxPool2d). */
+int unetk_bn_act_fwd(const void* y, void* a, void* pooled, int B, int H, int W, int C, const float* scale,
+                     const float* shift, const float* keep, int relu, int dtype, unetk_stream_t stream);
+int unetk_reduce_num_partials(int64_t npix);
+/* dy = BN'(relu'(keep * g)); dgamma/dbeta (nullable) (+)=.  partials: [num_partials][2][C], sums: [2][C] */
+int unetk_bn_act_bwd(const void* g, const void* y, void* dy, int B, int H, int W, int C,
+                     const float* scale, const float* shift, const float* mean, const float* invstd,
+                     const float* keep, int relu, float* dgamma, float* dbeta, int accumulate,
+                     float* partials, float* sums, int dtype, unetk_stream_t stream);
+/* da = dskip + route(dpooled to the first maximum of each 2x2 quad of a) */
+int unetk_pool_bwd(const void* a, const void* dpooled, const void* dskip, int ldskip, void* da, int B,
+                   int H, int W, int C, int dtype, unetk_stream_t stream);
+
+/* ---- F.interpolate(bilinear, align_corners=False) to the skip's size + torch.cat -----
+ * training.py:504-517 */
+int unetk_upsample_concat_fwd(const void* low, int h, int w, int C1, const void* skip, int ldskip, int C2,
+                              void* out, int B, int H, int W, int dtype, unetk_stream_t stream);
+int unetk_upsample_bwd(const void* dout, int ldout, int H, int W, void* dlow, int B, int h, int w, int C1,
+                       int dtype, unetk_stream_t stream);
+
+/* ---- final nn.Conv2d(C, Co, 1) with bias, NHWC in -> NCHW fp32 out --------------------
+ * training.py:482,520; swin_unet_model.py:611 */
+int unetk_head1x1_fwd(const void* x, int ldx, const float* w, const float* bias, float* out, int B, int H,
+                      int W, int C, int Co, int dtype, unetk_stream_t stream);
+int unetk_head1x1_bwd(const void* x, int ldx, const float* w, const float* dout, void* dx, float* dw,
+                      float* db, int B, int H, int W, int C, int Co, int accumulate, float* partials,
+                      int dtype, unetk_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNETK_H */

@@ -37,6 +37,46 @@ def draw_dropout_masks(batch: int, init_features: int, p: float = DROPOUT_P) -> 
     return masks
 
 
+def _r(t):
+    """Round to bfloat16 storage and back, with a straight-through gradient."""
+    return t + (t.to(torch.bfloat16).to(t.dtype) - t).detach()
+
+
+def _double_conv_bf16(sd, name, x, training, mask, new_stats):
+    """_double_conv with the roundings a bfloat16-storage pipeline performs.
+
+    Conv operands (activations, weights) and every stored activation are rounded to bf16;
+    accumulation, statistics and the normalisation arithmetic stay in fp32.  In training the
+    raw conv output is stored (rounded) before BatchNorm is applied to it, while the batch
+    statistics are taken from the unrounded accumulators; in eval the folded BatchNorm acts on
+    the accumulators directly.  This is the model the bf16 GPU path is held to tightly; its
+    distance from the fp32 model is the price of bf16 storage, not of the kernels.
+    """
+    for unit, (conv_i, bn_i) in enumerate(((0, 1), (3, 4))):
+        y32 = F.conv2d(x, _r(sd[f"{name}.{conv_i}.weight"]), None, padding=1)
+        g, b = sd[f"{name}.{bn_i}.weight"], sd[f"{name}.{bn_i}.bias"]
+        if training:
+            mean = y32.mean((0, 2, 3))
+            var = y32.var((0, 2, 3), unbiased=False)
+            n = y32.numel() / y32.shape[1]
+            new_stats[f"{name}.{bn_i}.running_mean"] = (
+                (1 - BN_MOMENTUM) * sd[f"{name}.{bn_i}.running_mean"] + BN_MOMENTUM * mean.detach())
+            new_stats[f"{name}.{bn_i}.running_var"] = (
+                (1 - BN_MOMENTUM) * sd[f"{name}.{bn_i}.running_var"]
+                + BN_MOMENTUM * var.detach() * (n / max(n - 1, 1)))
+            y = _r(y32)
+        else:
+            mean, var = sd[f"{name}.{bn_i}.running_mean"], sd[f"{name}.{bn_i}.running_var"]
+            y = y32
+        scale = g / torch.sqrt(var + BN_EPS)
+        shift = b - mean * scale
+        x = F.relu(y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+        if unit == 1 and training and mask is not None:   # the mask is applied before the single rounding
+            x = x * mask.view(mask.shape[0], mask.shape[1], 1, 1)
+        x = _r(x)
+    return x
+
+
 def _double_conv(sd, name, x, training, mask, new_stats):
     # reference training.py:522-531: conv3x3(no bias) -> BN -> ReLU, twice, then Dropout2d
     for conv_i, bn_i in ((0, 1), (3, 4)):
@@ -55,7 +95,7 @@ def _double_conv(sd, name, x, training, mask, new_stats):
 
 
 def unet_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, training: bool = False,
-                 dropout_masks: Optional[List[torch.Tensor]] = None
+                 dropout_masks: Optional[List[torch.Tensor]] = None, emulate_bf16: bool = False
                  ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
     """Returns (output (B,out,H,W), updated running statistics when training).
 
@@ -65,28 +105,31 @@ def unet_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, training: bool = 
     """
     new_stats: Dict[str, torch.Tensor] = {}
     m = dropout_masks if dropout_masks is not None else [None] * 9
-    e1 = _double_conv(sd, "encoder1", x, training, m[0], new_stats)
-    e2 = _double_conv(sd, "encoder2", F.max_pool2d(e1, 2, 2), training, m[1], new_stats)
-    e3 = _double_conv(sd, "encoder3", F.max_pool2d(e2, 2, 2), training, m[2], new_stats)
-    e4 = _double_conv(sd, "encoder4", F.max_pool2d(e3, 2, 2), training, m[3], new_stats)
-    d = _double_conv(sd, "bottleneck", F.max_pool2d(e4, 2, 2), training, m[4], new_stats)
+    block = _double_conv_bf16 if emulate_bf16 else _double_conv
+    rnd = _r if emulate_bf16 else (lambda t: t)
+    x = rnd(x)
+    e1 = block(sd, "encoder1", x, training, m[0], new_stats)
+    e2 = block(sd, "encoder2", F.max_pool2d(e1, 2, 2), training, m[1], new_stats)
+    e3 = block(sd, "encoder3", F.max_pool2d(e2, 2, 2), training, m[2], new_stats)
+    e4 = block(sd, "encoder4", F.max_pool2d(e3, 2, 2), training, m[3], new_stats)
+    d = block(sd, "bottleneck", F.max_pool2d(e4, 2, 2), training, m[4], new_stats)
     for i, (name, skip) in enumerate((("decoder4", e4), ("decoder3", e3),
                                       ("decoder2", e2), ("decoder1", e1))):
-        d = F.interpolate(d, size=skip.shape[2:], mode="bilinear", align_corners=False)
+        d = rnd(F.interpolate(d, size=skip.shape[2:], mode="bilinear", align_corners=False))
         d = torch.cat((d, skip), dim=1)
-        d = _double_conv(sd, name, d, training, m[5 + i], new_stats)
+        d = block(sd, name, d, training, m[5 + i], new_stats)
     out = F.conv2d(d, sd["conv.weight"], sd["conv.bias"])
     return out, new_stats
 
 
-def unet_fwd_bwd(sd, x, loss_fn, dropout_masks=None):
+def unet_fwd_bwd(sd, x, loss_fn, dropout_masks=None, emulate_bf16=False):
     """One training-mode forward + backward.  Returns (out, loss, grads by name, new stats)."""
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items()
               if v.is_floating_point() and not k.endswith(("running_mean", "running_var"))}
     full = dict(sd)
     full.update(params)
     xin = x.clone().requires_grad_(True)
-    out, stats = unet_forward(full, xin, True, dropout_masks)
+    out, stats = unet_forward(full, xin, True, dropout_masks, emulate_bf16)
     loss = loss_fn(out)
     loss.backward()
     grads = {k: p.grad for k, p in params.items()}

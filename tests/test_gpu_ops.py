@@ -1,0 +1,222 @@
+"""GPU parity tests, one per kernel family, through the C ABI (ctypes) against torch-CPU fp32.
+
+Tolerances (relative L2 over the whole tensor): float32 kernels 1e-4 (the north-star bound;
+most land near 1e-6), bfloat16 kernels 1e-2 for a single op (inputs are rounded to bf16 before
+both sides compute, so this measures the kernel, not the input rounding).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 1e-4, torch.bfloat16: 1e-2}
+
+
+def rel(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def rnd(shape, seed, dt, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.randn(shape, generator=g) * scale
+    return t.to(dt).float()     # values exactly representable in the compute dtype
+
+
+def nhwc(t, dt):
+    """(B,C,H,W) fp32 cpu -> (B,H,W,C) compute dtype on the GPU."""
+    return t.permute(0, 2, 3, 1).contiguous().to("cuda", dt)
+
+
+def nchw(t):
+    return t.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+CONV_SHAPES = [  # B, H, W, Ci, Co, ks
+    (2, 20, 33, 8, 16, 3),
+    (1, 16, 16, 48, 96, 3),
+    (1, 37, 18, 144, 48, 3),
+    (2, 8, 8, 96, 192, 3),
+    (1, 5, 3, 24, 8, 3),
+    (3, 9, 11, 64, 64, 1),
+    (1, 40, 40, 96, 384, 1),
+    (2, 7, 5, 32, 24, 1),
+]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_conv_fwd_dgrad_wgrad(dt, shape):
+    from unet_amd import ops
+    B, H, W, Ci, Co, ks = shape
+    x = rnd((B, Ci, H, W), 1, dt)
+    w = rnd((Co, Ci, ks, ks), 2, dt, (2.0 / (Ci * ks * ks)) ** 0.5)
+    gy = rnd((B, Co, H, W), 3, dt)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, None, padding=ks // 2)
+    ref.backward(gy)
+
+    xd = nhwc(x, dt)
+    pw = ops.PackedConv(w.cuda(), dt)
+    y, stats = ops.conv_fwd(xd, pw, want_stats=True)
+    torch.cuda.synchronize()
+    assert rel(nchw(y), ref) < TOL[dt]
+    # batch statistics from the epilogue
+    s = stats.double().sum(0).cpu()
+    assert rel(s[0], ref.double().sum((0, 2, 3))) < 1e-3 or ref.double().sum((0, 2, 3)).abs().max() < 1e-2
+    assert rel(s[1], (ref.double() ** 2).sum((0, 2, 3))) < (1e-4 if dt == torch.float32 else 1e-2)
+    # data gradient = same kernel with transposed, flipped weights
+    pwt = ops.PackedConv(w.cuda(), dt, transpose=True)
+    gd = nhwc(gy, dt)
+    dx, _ = ops.conv_fwd(gd, pwt)
+    assert rel(nchw(dx), xr.grad) < TOL[dt]
+    # weight gradient
+    dw = ops.conv_wgrad(xd, gd, Ci, Co, ks)
+    assert rel(dw.cpu(), wr.grad) < TOL[dt]
+    # accumulate flag
+    dw2 = ops.conv_wgrad(xd, gd, Ci, Co, ks, dw=dw.clone(), accumulate=True)
+    assert rel(dw2.cpu(), 2 * wr.grad) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_conv_epilogue_affine_relu_residual(dt):
+    from unet_amd import ops
+    B, H, W, Ci, Co = 2, 19, 21, 16, 32
+    x = rnd((B, Ci, H, W), 4, dt)
+    w = rnd((Co, Ci, 3, 3), 5, dt, 0.1)
+    sc = torch.rand(Co) + 0.5
+    sh = torch.randn(Co) * 0.3
+    ref = F.relu(F.conv2d(x, w, None, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    pw = ops.PackedConv(w.cuda(), dt)
+    y, _ = ops.conv_fwd(nhwc(x, dt), pw, scale=sc.cuda(), shift=sh.cuda(), act=1)
+    assert rel(nchw(y), ref) < TOL[dt]
+    # residual with per-sample keep scale and GELU, 1x1
+    w1 = rnd((Co, Ci, 1, 1), 6, dt, 0.2)
+    res = rnd((B, Co, H, W), 7, dt)
+    keep = torch.tensor([0.0, 1.25])
+    ref2 = res + keep.view(B, 1, 1, 1) * (F.conv2d(x, w1) + sh.view(1, -1, 1, 1))
+    pw1 = ops.PackedConv(w1.cuda(), dt)
+    y2, _ = ops.conv_fwd(nhwc(x, dt), pw1, shift=sh.cuda(), resid=nhwc(res, dt), resid_keep=keep.cuda())
+    assert rel(nchw(y2), ref2) < TOL[dt]
+    ref3 = F.gelu(F.conv2d(x, w1) + sh.view(1, -1, 1, 1))
+    y3, _ = ops.conv_fwd(nhwc(x, dt), pw1, shift=sh.cuda(), act=2)
+    assert rel(nchw(y3), ref3) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 16, 16, 16), (3, 9, 7, 48), (1, 32, 30, 96), (2, 5, 4, 768)])
+def test_bn_relu_dropout_pool_fwd_bwd(dt, shape):
+    from unet_amd import ops
+    B, H, W, C = shape
+    y = (rnd((B, C, H, W), 8, dt) * 1.5 + 0.3).to(dt).float()
+    gamma = torch.rand(C) + 0.5
+    beta = torch.randn(C) * 0.2
+    keep = (torch.rand(B, C) > 0.3).float() / 0.7
+    rm, rv = torch.randn(C) * 0.1, torch.rand(C) + 0.5
+    # reference
+    yr = y.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    z = F.batch_norm(yr, rm_ref, rv_ref, gr, br, True, 0.1, 1e-5)
+    a_ref = F.relu(z) * keep.view(B, C, 1, 1)
+    p_ref = F.max_pool2d(a_ref, 2, 2) if H >= 2 and W >= 2 else None
+    # kernels: statistics from a 1x1 identity-free path -> use conv epilogue substitute: compute partials by torch
+    yd = nhwc(y, dt)
+    stats = torch.stack([yd.float().sum((0, 1, 2)), (yd.float() ** 2).sum((0, 1, 2))]).view(1, 2, C)
+    rm_d, rv_d = rm.cuda(), rv.cuda()
+    mean, invstd, sc, sh = ops.bn_finalize(stats.contiguous(), B * H * W, gamma.cuda(), beta.cuda(), rm_d, rv_d)
+    assert rel(rm_d, rm_ref) < 1e-5 and rel(rv_d, rv_ref) < 1e-5
+    a, pooled = ops.bn_act_fwd(yd, sc, sh, keep.cuda(), relu=True, pool=p_ref is not None)
+    assert rel(nchw(a), a_ref) < TOL[dt]
+    if p_ref is not None:
+        assert rel(nchw(pooled), p_ref) < TOL[dt]
+        assert torch.equal(ops.maxpool2x2(a), pooled)
+    # backward
+    g = rnd((B, C, H, W), 9, dt)
+    a_ref.backward(g)
+    dy, dgamma, dbeta = ops.bn_act_bwd(nhwc(g, dt), yd, sc, sh, mean, invstd, keep.cuda(), relu=True)
+    tol = TOL[dt] * (3 if dt == torch.bfloat16 else 1)
+    assert rel(nchw(dy), yr.grad) < tol
+    assert rel(dgamma, gr.grad) < tol and rel(dbeta, br.grad) < tol
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 16, 16, 16), (1, 9, 7, 48), (2, 2, 2, 8)])
+def test_pool_bwd_first_max_and_skip(dt, shape):
+    from unet_amd import ops
+    B, H, W, C = shape
+    a = F.relu(rnd((B, C, H, W), 10, dt))          # many exact ties at 0
+    ar = a.clone().requires_grad_(True)
+    p = F.max_pool2d(ar, 2, 2)
+    gp = rnd(tuple(p.shape), 11, dt)
+    p.backward(gp)
+    skip = rnd((B, C + 8, H, W), 12, dt)            # skip gradient lives in channels [8:] of a wider buffer
+    sk = nhwc(skip, dt)
+    da = ops.pool_bwd(nhwc(a, dt), nhwc(gp, dt), sk[..., 8:])
+    want = ar.grad + skip[:, 8:]
+    assert rel(nchw(da), want) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("hw", [((8, 8), (16, 16)), ((6, 9), (12, 18)), ((12, 18), (25, 36)), ((1, 1), (3, 3)),
+                                ((3, 5), (7, 11))])
+def test_upsample_concat_fwd_bwd(dt, hw):
+    from unet_amd import ops
+    (h, w), (H, W) = hw
+    B, C1, C2 = 2, 16, 8
+    low = rnd((B, C1, h, w), 13, dt)
+    skip = rnd((B, C2, H, W), 14, dt)
+    lr = low.clone().requires_grad_(True)
+    ref = torch.cat((F.interpolate(lr, size=(H, W), mode="bilinear", align_corners=False), skip), 1)
+    g = rnd(tuple(ref.shape), 15, dt)
+    ref.backward(g)
+    out = ops.upsample_concat(nhwc(low, dt), nhwc(skip, dt))
+    assert rel(nchw(out), ref) < TOL[dt]
+    dlow = ops.upsample_bwd(nhwc(g, dt), C1, h, w)
+    assert rel(nchw(dlow), lr.grad) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("Co", [1, 3])
+def test_head1x1_fwd_bwd(dt, Co):
+    from unet_amd import ops
+    B, H, W, C = 2, 13, 17, 48
+    x = rnd((B, C, H, W), 16, dt)
+    w = torch.randn(Co, C, 1, 1) * 0.2
+    b = torch.randn(Co)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, br)
+    g = torch.randn(B, Co, H, W)
+    ref.backward(g)
+    xd = nhwc(x, dt)
+    out = ops.head1x1_fwd(xd, w.cuda(), b.cuda())
+    assert rel(out, ref) < 1e-5
+    dx, dw, db = ops.head1x1_bwd(xd, w.cuda(), g.cuda())
+    assert rel(nchw(dx), xr.grad) < TOL[dt]
+    assert rel(dw, wr.grad) < 1e-4 and rel(db, br.grad) < 1e-5
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_layout_roundtrip(dt):
+    from unet_amd import ops
+    x = rnd((2, 5, 7, 9), 17, dt)
+    h = ops.nchw_to_nhwc(x.cuda(), dt)
+    assert h.shape[-1] % (8 if dt == torch.bfloat16 else 4) == 0
+    assert torch.equal(h[..., :5].float().cpu(), x.permute(0, 2, 3, 1))
+    assert torch.count_nonzero(h[..., 5:]) == 0
+    assert torch.equal(ops.nhwc_to_nchw(h, 5).cpu(), x)
+
+
+def test_bad_arguments_raise():
+    from unet_amd import ops
+    x = torch.zeros((1, 4, 4, 6), device="cuda", dtype=torch.bfloat16)   # 6 channels: not a multiple of 8
+    pw = ops.PackedConv(torch.zeros(8, 8, 3, 3, device="cuda"), torch.bfloat16)
+    with pytest.raises(ValueError):
+        ops.conv_fwd(x, pw, Ci=6, Co=8)
+    with pytest.raises(RuntimeError):
+        ops.nchw_to_nhwc(torch.zeros(1, 1, 2, 2), torch.float32)   # CPU tensor: no fallback

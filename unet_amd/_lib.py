@@ -1,0 +1,113 @@
+"""ctypes binding of libunetk.so (the C ABI declared in include/unetk.h).
+
+There is no CPU fallback: if the library is missing every call raises.  Device memory and
+streams come from torch; the kernels take raw device pointers.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libunetk.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+OK, EINVAL, ESHAPE, EHIP = 0, -1, -2, -3
+
+
+class UnetkError(RuntimeError):
+    pass
+
+
+class UnetkMissing(ImportError):
+    pass
+
+
+P, I, L, F = c_void_p, c_int, c_int64, c_float
+
+# name -> (restype, argtypes); mirrors include/unetk.h one to one
+_SIGNATURES = {
+    "unetk_last_error": (c_char_p, []),
+    "unetk_version": (I, []),
+    "unetk_conv_pick_bn": (I, [I]),
+    "unetk_conv_packed_elems": (L, [I, I, I, I, I]),
+    "unetk_conv_pack_weight": (I, [P, P, I, I, I, I, I, I, P]),
+    "unetk_conv_num_tiles": (I, [I, I, I, I]),
+    "unetk_conv_fwd": (I, [P, I, P, P, I, I, I, I, I, I, I, I, I, P, P, P, I, P, I, P, P]),
+    "unetk_conv_wgrad_workspace_bytes": (L, [I, I, I, I, I, I, I]),
+    "unetk_conv_wgrad": (I, [P, I, P, I, P, I, I, I, I, I, I, I, P, L, I, P]),
+    "unetk_nchw_to_nhwc": (I, [P, P, I, I, I, I, I, I, P]),
+    "unetk_nhwc_to_nchw": (I, [P, I, P, I, I, I, I, I, P]),
+    "unetk_bn_finalize": (I, [P, I, I, L, P, P, F, F, P, P, P, P, P, P, P]),
+    "unetk_bn_fold_eval": (I, [P, P, P, P, F, P, P, P, I, P]),
+    "unetk_bn_act_fwd": (I, [P, P, P, I, I, I, I, P, P, P, I, I, P]),
+    "unetk_reduce_num_partials": (I, [L]),
+    "unetk_bn_act_bwd": (I, [P, P, P, I, I, I, I, P, P, P, P, P, I, P, P, I, P, P, I, P]),
+    "unetk_pool_bwd": (I, [P, P, P, I, P, I, I, I, I, I, P]),
+    "unetk_upsample_concat_fwd": (I, [P, I, I, I, P, I, I, P, I, I, I, I, P]),
+    "unetk_upsample_bwd": (I, [P, I, I, I, P, I, I, I, I, I, P]),
+    "unetk_head1x1_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, P]),
+    "unetk_head1x1_bwd": (I, [P, I, P, P, P, P, P, I, I, I, I, I, I, P, I, P]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Names the header declares; used by the CPU test that the library exports them all."""
+    return sorted(_SIGNATURES)
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise UnetkMissing(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().unetk_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int):
+    if rc == OK:
+        return
+    msg = last_error()
+    if rc in (EINVAL, ESHAPE):
+        raise ValueError(f"unetk: {msg}")
+    raise UnetkError(f"unetk (code {rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (or None)."""
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr())
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    raise ValueError(f"unetk: unsupported compute dtype {dt} (float32 or bfloat16)")
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args))

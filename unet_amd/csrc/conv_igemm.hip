@@ -1,0 +1,403 @@
+// Implicit-GEMM convolution (3x3 pad 1, or 1x1) on MFMA for gfx950, NHWC activations.
+//
+//   out[b,y,x,co] = sum_{ky,kx,ci} in[b,y+ky-1,x+kx-1,ci] * w[co,ci,ky,kx]
+//
+// GEMM view: M = pixels, N = Cout, K = taps*Cin.  A workgroup (4 waves) owns a 16x16
+// pixel tile (3x3) or 256 consecutive pixels (1x1) and BN = NT*16 output channels; wave
+// w owns tile rows 4w..4w+3 (four 16-pixel MFMA row tiles) times all NT column tiles.
+// The K loop runs over channel chunks of KC (32 bf16 / 16 f32 = 64 bytes per pixel):
+// the 18x18 input halo of the chunk is staged in LDS once and re-read by all nine
+// taps as shifted windows, so global->LDS traffic is ~1.27x the tile instead of 9x.
+// Weights come pre-packed as [n-block][chunk][tap][BN][KC] so a kernel row's three
+// taps are one contiguous slab.
+//
+// Epilogue (all optional): per-channel partial sums / sums of squares of the fp32
+// accumulators over the tile's valid pixels (BatchNorm batch statistics, reduced later
+// in a deterministic order), y*scale+shift (folded BatchNorm or bias), ReLU or GELU,
+// residual add with a per-sample scale.  The result goes through a per-wave LDS
+// staging tile so that global stores are 16-byte vectors along the channel axis.
+//
+// Used for: forward conv (reference training.py:523-529), data-gradient conv (same
+// kernel, weights packed transposed and flipped), Swin linear layers as 1x1.
+#include "common.h"
+
+namespace {
+
+template <typename T> struct MMA;
+template <> struct MMA<bf16> {
+  static constexpr int KC = 32;      // channels per 64-byte chunk row
+  static constexpr int KSTEPS = 1;   // MFMA k-steps per chunk
+  using frag = bf16x8;
+  static __device__ __forceinline__ frag load(const char* row, int ks, int lane) {
+    return *reinterpret_cast<const frag*>(row + (lane >> 4) * 16);
+  }
+  static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct MMA<float> {
+  static constexpr int KC = 16;
+  static constexpr int KSTEPS = 4;
+  using frag = float;
+  static __device__ __forceinline__ frag load(const char* row, int ks, int lane) {
+    return *reinterpret_cast<const float*>(row + (ks * 4 + (lane >> 4)) * 4);
+  }
+  static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+};
+
+struct ConvArgs {
+  const void* in;
+  const void* w;
+  void* out;
+  float* stats;            // [tiles][2][Co] or null
+  const float* ep_scale;   // [Co] or null (=1)
+  const float* ep_shift;   // [Co] or null (=0)
+  const void* resid;       // residual (same layout as out, ld = ldres) or null
+  const float* resid_keep; // per-sample scale applied to the conv result before the add, or null
+  int ldin, ldout, ldres;
+  int B, H, W, Ci, Co;
+  int nchunks;
+  int act;                 // 0 none, 1 relu, 2 gelu(erf)
+  int tiles_x, tiles_y;
+};
+
+constexpr int ROWB = 80;   // LDS bytes per staged row: 64 data + 16 pad
+
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+template <typename T, int NT, int KS>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+  using M = MMA<T>;
+  constexpr int KC = M::KC;
+  constexpr int EPP = 16 / (int)sizeof(T);     // elements per 16-byte part
+  constexpr int BN = NT * 16;
+  constexpr int HALO = (KS == 3) ? 18 : 16;
+  constexpr int HPIX = HALO * HALO;
+  constexpr int TAPS = KS * KS;
+  constexpr int WROWS = KS * BN;
+  constexpr int MAIN_BYTES = (HPIX + WROWS) * ROWB;
+  constexpr int STAGE_BYTES = 4 * 16 * BN * (int)sizeof(T);
+  constexpr int LDS_BYTES = MAIN_BYTES > STAGE_BYTES ? MAIN_BYTES : STAGE_BYTES;
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+  __shared__ float red[4][2][BN];
+  char* lds_halo = lds;
+  char* lds_w = lds + HPIX * ROWB;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int nb = blockIdx.y;
+  const int n0 = nb * BN;
+  const T* in = reinterpret_cast<const T*>(a.in);
+  const T* wp = reinterpret_cast<const T*>(a.w);
+  T* out = reinterpret_cast<T*>(a.out);
+
+  // tile coordinates
+  int b = 0, y0 = 0, x0 = 0;
+  long p0 = 0;                       // first flat pixel (1x1 mode)
+  const long npix = (long)a.B * a.H * a.W;
+  if (KS == 3) {
+    int t = blockIdx.x;
+    int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    int ty = t % a.tiles_y;
+    b = t / a.tiles_y;
+    y0 = ty * 16;
+    x0 = tx * 16;
+  } else {
+    p0 = (long)blockIdx.x * 256;
+  }
+
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int ch = 0; ch < a.nchunks; ++ch) {
+    const int c0 = ch * KC;
+    __syncthreads();   // every wave is done reading the previous chunk
+    // ---- stage the input halo of this chunk
+    for (int idx = tid; idx < HPIX * 4; idx += 256) {
+      const int pix = idx >> 2, part = idx & 3;
+      const int c = c0 + part * EPP;
+      Vec16<T> v = zero16<T>();
+      if (KS == 3) {
+        const int hy = pix / HALO, hx = pix - hy * HALO;
+        const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.Ci)
+          v = load16(in + (((long)b * a.H + gy) * a.W + gx) * a.ldin + c);
+      } else {
+        const long p = p0 + pix;
+        if (p < npix && c < a.Ci) v = load16(in + p * a.ldin + c);
+      }
+      store16(reinterpret_cast<T*>(lds_halo + pix * ROWB + part * 16), v);
+    }
+#pragma unroll 1
+    for (int ky = 0; ky < KS; ++ky) {
+      if (ky > 0) __syncthreads();   // previous kernel row's weights no longer read
+      const T* wsrc = wp + ((((long)nb * a.nchunks + ch) * TAPS + ky * KS) * BN) * KC;
+      for (int idx = tid; idx < WROWS * 4; idx += 256) {
+        const int row = idx >> 2, part = idx & 3;
+        store16(reinterpret_cast<T*>(lds_w + row * ROWB + part * 16),
+                load16(wsrc + row * KC + part * EPP));
+      }
+      __syncthreads();
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) {
+#pragma unroll
+        for (int ks = 0; ks < M::KSTEPS; ++ks) {
+          typename M::frag af[4], bfr[NT];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int prow = (KS == 3) ? ((4 * wave + i + ky) * HALO + kx + (lane & 15))
+                                       : ((4 * wave + i) * 16 + (lane & 15));
+            af[i] = M::load(lds_halo + prow * ROWB, ks, lane);
+          }
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            bfr[j] = M::load(lds_w + (kx * BN + j * 16 + (lane & 15)) * ROWB, ks, lane);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = M::mma(af[i], bfr[j], acc[i][j]);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue.  C layout: column (channel) = lane&15, row (pixel) = 4*(lane>>4)+r.
+  const int cl = lane & 15, pg = lane >> 4;
+  bool rowvalid[4];
+  bool colvalid[4];
+  long pixbase[4];   // flat pixel index of (tile row i, tile col 0)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (KS == 3) {
+      const int gy = y0 + 4 * wave + i;
+      rowvalid[i] = gy < a.H;
+      pixbase[i] = ((long)b * a.H + gy) * a.W + x0;
+    } else {
+      pixbase[i] = p0 + (4 * wave + i) * 16;
+      rowvalid[i] = true;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (KS == 3) colvalid[r] = (x0 + 4 * pg + r) < a.W;
+    else colvalid[r] = true;
+  }
+  auto pixel_valid = [&](int i, int r) -> bool {
+    if (KS == 3) return rowvalid[i] && colvalid[r];
+    return (pixbase[i] + 4 * pg + r) < npix;
+  };
+
+  if (a.stats != nullptr) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (pixel_valid(i, r)) {
+            const float v = acc[i][j][r];
+            s += v;
+            q += v * v;
+          }
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      q += __shfl_xor(q, 16, 64);
+      q += __shfl_xor(q, 32, 64);
+      if (pg == 0) {
+        red[wave][0][j * 16 + cl] = s;
+        red[wave][1][j * 16 + cl] = q;
+      }
+    }
+  }
+  __syncthreads();   // all MFMA reads of lds done; red[] visible
+  if (a.stats != nullptr && tid < BN && n0 + tid < a.Co) {
+    const float s = red[0][0][tid] + red[1][0][tid] + red[2][0][tid] + red[3][0][tid];
+    const float q = red[0][1][tid] + red[1][1][tid] + red[2][1][tid] + red[3][1][tid];
+    float* st = a.stats + (long)blockIdx.x * 2 * a.Co;
+    st[n0 + tid] = s;
+    st[a.Co + n0 + tid] = q;
+  }
+
+  float esc[NT], esh[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int c = n0 + j * 16 + cl;
+    esc[j] = (a.ep_scale != nullptr && c < a.Co) ? a.ep_scale[c] : 1.f;
+    esh[j] = (a.ep_shift != nullptr && c < a.Co) ? a.ep_shift[c] : 0.f;
+  }
+
+  T* stage = reinterpret_cast<T*>(lds) + wave * 16 * BN;
+  constexpr int PPP = BN / EPP;            // 16-byte parts per staged pixel
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i > 0) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[i][j][r] * esc[j] + esh[j];
+        if (a.act == 1) v = fmaxf(v, 0.f);
+        else if (a.act == 2) v = gelu_erf(v);
+        stage[(4 * pg + r) * BN + j * 16 + cl] = from_f32<T>(v);
+      }
+    __syncthreads();
+    for (int part = lane; part < 16 * PPP; part += 64) {
+      const int pc = part / PPP, cp = part - pc * PPP;
+      const int c = n0 + cp * EPP;
+      bool ok;
+      long p = pixbase[i] + pc;
+      if (KS == 3) ok = rowvalid[i] && (x0 + pc) < a.W;
+      else ok = p < npix;
+      if (ok && c < a.Co) {
+        Vec16<T> v = load16(stage + pc * BN + cp * EPP);
+        if (a.resid != nullptr) {
+          const T* rs = reinterpret_cast<const T*>(a.resid) + p * a.ldres + c;
+          Vec16<T> rv = load16(rs);
+          float keep = 1.f;
+          if (a.resid_keep != nullptr) keep = a.resid_keep[p / ((long)a.H * a.W)];
+#pragma unroll
+          for (int e = 0; e < EPP; ++e)
+            v.v[e] = from_f32<T>(to_f32(rv.v[e]) + keep * to_f32(v.v[e]));
+        }
+        store16(out + p * a.ldout + c, v);
+      }
+    }
+  }
+}
+
+// ---- weight packing: [Co][Ci][KS][KS] f32 -> [nblk][nchunk][tap][BN][KC] T
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ dst, int Co, int Ci,
+                                   int ks, int bn, int kc, int nchunks, int transpose, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int taps = ks * ks;
+  long t = idx;
+  const int k = t % kc;
+  t /= kc;
+  const int row = t % bn;
+  t /= bn;
+  const int tap = t % taps;
+  t /= taps;
+  const int ch = t % nchunks;
+  const int nb = t / nchunks;
+  const int n = nb * bn + row;   // output channel of the packed conv
+  const int c = ch * kc + k;     // input channel of the packed conv
+  float v = 0.f;
+  if (!transpose) {
+    if (n < Co && c < Ci) v = w[((long)n * Ci + c) * taps + tap];
+  } else {
+    // data-gradient conv: out channel n = original ci, in channel c = original co, taps flipped
+    if (n < Ci && c < Co) v = w[((long)c * Ci + n) * taps + (taps - 1 - tap)];
+  }
+  dst[idx] = from_f32<T>(v);
+}
+
+template <typename T, int KS>
+int launch_conv(const ConvArgs& a, int bn, hipStream_t stream) {
+  const long npix = (long)a.B * a.H * a.W;
+  dim3 grid;
+  grid.x = (KS == 3) ? a.B * a.tiles_x * a.tiles_y : cdiv(npix, 256);
+  grid.y = cdiv(a.Co, bn);
+  grid.z = 1;
+  switch (bn) {
+    case 32: hipLaunchKernelGGL((conv_igemm_kernel<T, 2, KS>), grid, dim3(256), 0, stream, a); break;
+    case 48: hipLaunchKernelGGL((conv_igemm_kernel<T, 3, KS>), grid, dim3(256), 0, stream, a); break;
+    case 64: hipLaunchKernelGGL((conv_igemm_kernel<T, 4, KS>), grid, dim3(256), 0, stream, a); break;
+    case 96: hipLaunchKernelGGL((conv_igemm_kernel<T, 6, KS>), grid, dim3(256), 0, stream, a); break;
+    default:
+      unetk_set_error("conv: unsupported channel block %d (32, 48, 64 or 96)", bn);
+      return UNETK_EINVAL;
+  }
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+inline int kc_of(int dtype) { return dtype == UNETK_BF16 ? 32 : 16; }
+inline int epp_of(int dtype) { return dtype == UNETK_BF16 ? 8 : 4; }
+
+}  // namespace
+
+extern "C" {
+
+int unetk_conv_pick_bn(int Co) {
+  if (Co % 96 == 0) return 96;
+  if (Co % 64 == 0) return 64;
+  if (Co % 48 == 0) return 48;
+  if (Co <= 32) return 32;
+  if (Co <= 48) return 48;
+  if (Co <= 64) return 64;
+  return (Co % 32 == 0) ? 32 : 96;
+}
+
+int64_t unetk_conv_packed_elems(int Co, int Ci, int ks, int bn, int dtype) {
+  const int kc = kc_of(dtype);
+  return (int64_t)cdiv(Co, bn) * cdiv(Ci, kc) * ks * ks * bn * kc;
+}
+
+int unetk_conv_pack_weight(const float* w, void* packed, int Co, int Ci, int ks, int bn, int dtype,
+                           int transpose, hipStream_t stream) {
+  UNETK_CHECK_ARG(w && packed, "conv_pack_weight: null pointer");
+  UNETK_CHECK_ARG(ks == 1 || ks == 3, "conv_pack_weight: kernel size %d (1 or 3)", ks);
+  UNETK_CHECK_ARG(dtype == UNETK_F32 || dtype == UNETK_BF16, "conv_pack_weight: bad dtype %d", dtype);
+  const int pCo = transpose ? Ci : Co, pCi = transpose ? Co : Ci;
+  const int kc = kc_of(dtype);
+  const int nchunks = cdiv(pCi, kc);
+  const long total = unetk_conv_packed_elems(pCo, pCi, ks, bn, dtype);
+  const int grid = cdiv(total, 256);
+  if (dtype == UNETK_BF16)
+    hipLaunchKernelGGL(pack_weight_kernel<bf16>, dim3(grid), dim3(256), 0, stream, w, (bf16*)packed, Co,
+                       Ci, ks, bn, kc, nchunks, transpose, total);
+  else
+    hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(grid), dim3(256), 0, stream, w, (float*)packed,
+                       Co, Ci, ks, bn, kc, nchunks, transpose, total);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_conv_num_tiles(int B, int H, int W, int ks) {
+  if (ks == 3) return B * cdiv(H, 16) * cdiv(W, 16);
+  return cdiv((long)B * H * W, 256);
+}
+
+int unetk_conv_fwd(const void* in, int ldin, const void* wpacked, void* out, int ldout, int B, int H,
+                   int W, int Ci, int Co, int ks, int bn, int dtype, float* stats,
+                   const float* ep_scale, const float* ep_shift, int act, const void* resid, int ldres,
+                   const float* resid_keep, hipStream_t stream) {
+  UNETK_CHECK_ARG(in && wpacked && out, "conv_fwd: null pointer");
+  UNETK_CHECK_ARG(ks == 1 || ks == 3, "conv_fwd: kernel size %d (1 or 3)", ks);
+  UNETK_CHECK_ARG(dtype == UNETK_F32 || dtype == UNETK_BF16, "conv_fwd: bad dtype %d", dtype);
+  UNETK_CHECK_ARG(B > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0, "conv_fwd: bad shape");
+  const int epp = epp_of(dtype);
+  UNETK_CHECK_ARG(Ci % epp == 0 && Co % epp == 0 && ldin % epp == 0 && ldout % epp == 0,
+                  "conv_fwd: channels and strides must be multiples of %d (Ci=%d Co=%d ldin=%d ldout=%d)",
+                  epp, Ci, Co, ldin, ldout);
+  UNETK_CHECK_ARG(ldin >= Ci && ldout >= Co, "conv_fwd: stride smaller than channel count");
+  UNETK_CHECK_ARG(((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)wpacked % 16) == 0,
+                  "conv_fwd: pointers must be 16-byte aligned");
+  UNETK_CHECK_ARG(resid == nullptr || (ldres % epp == 0 && ((uintptr_t)resid % 16) == 0),
+                  "conv_fwd: residual misaligned");
+  ConvArgs a;
+  a.in = in; a.w = wpacked; a.out = out; a.stats = stats;
+  a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.resid = resid; a.resid_keep = resid_keep;
+  a.ldin = ldin; a.ldout = ldout; a.ldres = ldres;
+  a.B = B; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
+  a.nchunks = cdiv(Ci, kc_of(dtype));
+  a.act = act;
+  a.tiles_x = cdiv(W, 16); a.tiles_y = cdiv(H, 16);
+  if (dtype == UNETK_BF16)
+    return ks == 3 ? launch_conv<bf16, 3>(a, bn, stream) : launch_conv<bf16, 1>(a, bn, stream);
+  return ks == 3 ? launch_conv<float, 3>(a, bn, stream) : launch_conv<float, 1>(a, bn, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,271 @@
+// Weight-gradient of the 3x3 (pad 1) / 1x1 convolution on MFMA for gfx950.
+//
+//   dw[co,ci,ky,kx] = sum_{b,y,x} dy[b,y,x,co] * in[b,y+ky-1,x+kx-1,ci]
+//
+// GEMM view: M = Cout, N = taps*Cin, K = pixels.  Both operands are stored
+// pixel-major (NHWC), i.e. K is the slow axis of both, while an MFMA fragment wants
+// K contiguous per lane.  For bf16 the fragments are therefore read from LDS with the
+// transposing ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group); the f32
+// MFMA (16x16x4) takes one element per lane and needs no transpose.
+//
+// A workgroup (4 waves) owns BM = MT*16 output channels x one 32-channel input chunk x
+// all taps, and walks a strided list of pixel tiles (TR x TW pixels, TR*TW*sizeof(T)
+// = 512 B... 256 px bf16 / 128 px f32).  Per tile the dy tile and the input halo of the
+// chunk are staged in LDS once; every tap is a shifted window of the same halo.
+// Waves split the work as (16-channel half of the chunk) x (even/odd k-steps), and
+// each wave writes its own fp32 partial into a slab [2*S][Co_pad][taps][Ci_pad];
+// a second kernel sums the slabs in a fixed order (bitwise reproducible, no atomics)
+// and writes the [Co][Ci][KS][KS] fp32 gradient.
+#include "common.h"
+
+namespace {
+
+struct WgradArgs {
+  const void* in;
+  const void* dy;
+  float* slab;
+  int ldin, lddy;
+  int B, H, W, Ci, Co;
+  int Ci_pad, Co_pad;
+  int tiles_x, tiles_y, ntiles, nsplit;
+};
+
+constexpr int row_bytes_bf16(int bytes) { return ((bytes + 31) / 64) * 64 + 32; }   // == 32 mod 64
+constexpr int row_bytes_f32(int bytes) { return ((bytes + 63) / 128) * 128 + 64; }  // == 64 mod 128
+
+__device__ __forceinline__ bf16x8 tr_read8(const char* p0, const char* p1) {
+  short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, p0));
+  short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, p1));
+  typedef __attribute__((ext_vector_type(8))) short short8v;
+  short8v r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+template <typename T, int MT, int TW, int KS>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  constexpr bool BF = sizeof(T) == 2;
+  constexpr int EPP = 16 / (int)sizeof(T);
+  constexpr int TPIX = BF ? 256 : 128;          // pixels per tile
+  constexpr int TR = TPIX / TW;
+  constexpr int BM = MT * 16;
+  constexpr int KCI = 32;                       // input channels per block
+  constexpr int TAPS = KS * KS;
+  constexpr int HW_ = (KS == 3) ? TW + 2 : TW;  // halo width
+  constexpr int HH_ = (KS == 3) ? TR + 2 : TR;
+  constexpr int RBD = BF ? row_bytes_bf16(BM * 2) : row_bytes_f32(BM * 4);
+  constexpr int RBH = BF ? row_bytes_bf16(KCI * 2) : row_bytes_f32(KCI * 4);
+  constexpr int PPD = BM / EPP;                 // 16-byte parts per dy row
+  constexpr int PPH = KCI / EPP;
+  __shared__ __attribute__((aligned(16))) char lds[TPIX * RBD + HH_ * HW_ * RBH];
+  char* lds_dy = lds;
+  char* lds_h = lds + TPIX * RBD;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave & 1, wk = wave >> 1;
+  const int ci0 = blockIdx.x * KCI;
+  const int co0 = blockIdx.y * BM;
+  const T* in = reinterpret_cast<const T*>(a.in);
+  const T* dy = reinterpret_cast<const T*>(a.dy);
+
+  f32x4 acc[MT][TAPS];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, p4 = li & 3;
+
+  for (int tile = blockIdx.z; tile < a.ntiles; tile += a.nsplit) {
+    int t = tile;
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int b = t / a.tiles_y;
+    const int y0 = ty * TR, x0 = tx * TW;
+    __syncthreads();
+    // dy tile: [pixel][BM channels]
+    for (int idx = tid; idx < TPIX * PPD; idx += 256) {
+      const int pix = idx / PPD, part = idx - pix * PPD;
+      const int tr = pix / TW, tc = pix - tr * TW;
+      const int gy = y0 + tr, gx = x0 + tc;
+      const int c = co0 + part * EPP;
+      Vec16<T> v = zero16<T>();
+      if (gy < a.H && gx < a.W && c < a.Co)
+        v = load16(dy + (((long)b * a.H + gy) * a.W + gx) * a.lddy + c);
+      store16(reinterpret_cast<T*>(lds_dy + pix * RBD + part * 16), v);
+    }
+    // input halo: [(TR+2)*(TW+2) pixels][32 channels]
+    for (int idx = tid; idx < HH_ * HW_ * PPH; idx += 256) {
+      const int pix = idx / PPH, part = idx - pix * PPH;
+      const int hy = pix / HW_, hx = pix - hy * HW_;
+      const int gy = y0 + hy - (KS == 3 ? 1 : 0), gx = x0 + hx - (KS == 3 ? 1 : 0);
+      const int c = ci0 + part * EPP;
+      Vec16<T> v = zero16<T>();
+      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.Ci)
+        v = load16(in + (((long)b * a.H + gy) * a.W + gx) * a.ldin + c);
+      store16(reinterpret_cast<T*>(lds_h + pix * RBH + part * 16), v);
+    }
+    __syncthreads();
+
+    if constexpr (BF) {
+      // k-step = 32 consecutive tile pixels; this wave takes steps wk, wk+2, ...
+#pragma unroll 1
+      for (int ks = wk; ks < TPIX / 32; ks += 2) {
+        // the two 4-pixel groups this lane addresses for the transposing read
+        const int pk0 = ks * 32 + 8 * g + q;      // rows q of block kk=0
+        const int pk1 = pk0 + 4;                  // block kk=1
+        bf16x8 af[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          af[m] = tr_read8(lds_dy + pk0 * RBD + (m * 16 + 4 * p4) * 2,
+                           lds_dy + pk1 * RBD + (m * 16 + 4 * p4) * 2);
+        const int r0 = pk0 / TW, c0_ = pk0 - r0 * TW;
+        const int r1 = pk1 / TW, c1_ = pk1 - r1 * TW;
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < KS; ++kx) {
+            const char* h0 = lds_h + ((r0 + ky) * HW_ + c0_ + kx) * RBH + (wn * 16 + 4 * p4) * 2;
+            const char* h1 = lds_h + ((r1 + ky) * HW_ + c1_ + kx) * RBH + (wn * 16 + 4 * p4) * 2;
+            const bf16x8 bfr = tr_read8(h0, h1);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+              acc[m][ky * KS + kx] =
+                  __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr, acc[m][ky * KS + kx], 0, 0, 0);
+          }
+      }
+    } else {
+      // k-step = 4 consecutive tile pixels; A[m=lane&15][k=lane>>4], B[k=lane>>4][n=lane&15]
+#pragma unroll 1
+      for (int ks = wk; ks < TPIX / 4; ks += 2) {
+        const int pk = ks * 4 + g;
+        const int r0 = pk / TW, c0_ = pk - r0 * TW;
+        float af[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          af[m] = *reinterpret_cast<const float*>(lds_dy + pk * RBD + (m * 16 + li) * 4);
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < KS; ++kx) {
+            const float bv = *reinterpret_cast<const float*>(
+                lds_h + ((r0 + ky) * HW_ + c0_ + kx) * RBH + (wn * 16 + li) * 4);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+              acc[m][ky * KS + kx] =
+                  __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bv, acc[m][ky * KS + kx], 0, 0, 0);
+          }
+      }
+    }
+  }
+
+  // slab[(2*z + wk)][co][tap][ci]; C layout: col (ci) = lane&15, row (co) = 4*(lane>>4)+r
+  float* slab = a.slab + (long)(2 * blockIdx.z + wk) * a.Co_pad * TAPS * a.Ci_pad;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + m * 16 + 4 * g + r;
+        const int ci = ci0 + wn * 16 + li;
+        slab[((long)co * TAPS + t) * a.Ci_pad + ci] = acc[m][t][r];
+      }
+}
+
+// dw[co][ci][tap] (+)= sum_s slab[s][co][tap][ci]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nslab,
+                                    int Co, int Ci, int Co_pad, int Ci_pad, int taps, int accumulate) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)Co * taps * Ci;
+  if (idx >= total) return;
+  const int ci = idx % Ci;
+  const int tap = (idx / Ci) % taps;
+  const int co = idx / ((long)Ci * taps);
+  const long stride = (long)Co_pad * taps * Ci_pad;
+  const float* p = slab + ((long)co * taps + tap) * Ci_pad + ci;
+  float s = 0.f;
+  for (int i = 0; i < nslab; ++i) s += p[i * stride];
+  float* d = dw + ((long)co * Ci + ci) * taps + tap;
+  *d = accumulate ? (*d + s) : s;
+}
+
+struct WgradPlan {
+  int mt, tw, tpix, tr, tiles_x, tiles_y, ntiles, nsplit, Co_pad, Ci_pad;
+};
+
+WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int dtype) {
+  WgradPlan p;
+  p.mt = (Co % 48 == 0) ? 3 : ((Co % 64 == 0 || Co > 48) ? 4 : (Co > 32 ? 3 : 2));
+  p.tw = (W <= 16) ? 16 : 32;
+  p.tpix = dtype == UNETK_BF16 ? 256 : 128;
+  p.tr = p.tpix / p.tw;
+  p.tiles_x = cdiv(W, p.tw);
+  p.tiles_y = cdiv(H, p.tr);
+  p.ntiles = B * p.tiles_x * p.tiles_y;
+  p.Co_pad = cdiv(Co, p.mt * 16) * p.mt * 16;
+  p.Ci_pad = cdiv(Ci, 32) * 32;
+  const int gxy = (p.Ci_pad / 32) * (p.Co_pad / (p.mt * 16));
+  int s = 1536 / gxy;
+  if (s < 1) s = 1;
+  if (s > p.ntiles) s = p.ntiles;
+  p.nsplit = s;
+  return p;
+}
+
+template <typename T, int KS>
+int launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t stream) {
+  dim3 grid(p.Ci_pad / 32, p.Co_pad / (p.mt * 16), p.nsplit);
+#define WG_CASE(MT_, TW_)                                                                         \
+  if (p.mt == MT_ && p.tw == TW_) {                                                               \
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, MT_, TW_, KS>), grid, dim3(256), 0, stream, a);      \
+    UNETK_CHECK_LAUNCH();                                                                         \
+    return UNETK_OK;                                                                              \
+  }
+  WG_CASE(2, 16) WG_CASE(2, 32) WG_CASE(3, 16) WG_CASE(3, 32) WG_CASE(4, 16) WG_CASE(4, 32)
+#undef WG_CASE
+  unetk_set_error("conv_wgrad: no kernel for mt=%d tw=%d", p.mt, p.tw);
+  return UNETK_EINVAL;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t unetk_conv_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Co, int ks, int dtype) {
+  const WgradPlan p = plan_wgrad(B, H, W, Ci, Co, dtype);
+  return (int64_t)2 * p.nsplit * p.Co_pad * ks * ks * p.Ci_pad * 4;
+}
+
+int unetk_conv_wgrad(const void* in, int ldin, const void* dy, int lddy, float* dw, int B, int H, int W,
+                     int Ci, int Co, int ks, int dtype, void* workspace, int64_t workspace_bytes,
+                     int accumulate, hipStream_t stream) {
+  UNETK_CHECK_ARG(in && dy && dw && workspace, "conv_wgrad: null pointer");
+  UNETK_CHECK_ARG(ks == 1 || ks == 3, "conv_wgrad: kernel size %d (1 or 3)", ks);
+  UNETK_CHECK_ARG(dtype == UNETK_F32 || dtype == UNETK_BF16, "conv_wgrad: bad dtype %d", dtype);
+  const int epp = dtype == UNETK_BF16 ? 8 : 4;
+  UNETK_CHECK_ARG(Ci % epp == 0 && Co % epp == 0 && ldin % epp == 0 && lddy % epp == 0,
+                  "conv_wgrad: channels and strides must be multiples of %d", epp);
+  UNETK_CHECK_ARG(((uintptr_t)in % 16) == 0 && ((uintptr_t)dy % 16) == 0, "conv_wgrad: misaligned pointer");
+  const WgradPlan p = plan_wgrad(B, H, W, Ci, Co, dtype);
+  const int64_t need = unetk_conv_wgrad_workspace_bytes(B, H, W, Ci, Co, ks, dtype);
+  UNETK_CHECK_ARG(workspace_bytes >= need, "conv_wgrad: workspace %lld < %lld bytes",
+                  (long long)workspace_bytes, (long long)need);
+  WgradArgs a;
+  a.in = in; a.dy = dy; a.slab = (float*)workspace; a.ldin = ldin; a.lddy = lddy;
+  a.B = B; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.Ci_pad = p.Ci_pad; a.Co_pad = p.Co_pad;
+  a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.ntiles = p.ntiles; a.nsplit = p.nsplit;
+  int rc;
+  if (dtype == UNETK_BF16)
+    rc = ks == 3 ? launch_wgrad<bf16, 3>(a, p, stream) : launch_wgrad<bf16, 1>(a, p, stream);
+  else
+    rc = ks == 3 ? launch_wgrad<float, 3>(a, p, stream) : launch_wgrad<float, 1>(a, p, stream);
+  if (rc != UNETK_OK) return rc;
+  const long total = (long)Co * ks * ks * Ci;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, a.slab, dw,
+                     2 * p.nsplit, Co, Ci, p.Co_pad, p.Ci_pad, ks * ks, accumulate);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,738 @@
+// HBM-bound kernels around the convolutions (gfx950): layout changes, BatchNorm statistics,
+// BatchNorm+ReLU(+Dropout2d mask)(+2x2 max-pool) forward and backward, bilinear resize fused
+// with the skip concat and its backward, and the final 1x1 convolution.
+//
+// Activations are NHWC with the channel axis innermost, so every thread moves 16-byte
+// vectors (8 bf16 / 4 f32) of consecutive channels and consecutive threads cover
+// consecutive channel groups of one pixel: fully coalesced.  All arithmetic is fp32.
+// Per-channel reductions write per-workgroup partials that a second kernel sums in a
+// fixed order (in double), so results are bitwise reproducible; there are no atomics.
+#include "common.h"
+
+namespace {
+
+constexpr int RED_THREADS = 256;
+
+// ------------------------------------------------------------------ layout changes
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int B, int C,
+                                    int H, int W, int ld) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * H * W * ld;
+  if (idx >= total) return;
+  const int c = idx % ld;
+  const long p = idx / ld;
+  const long hw = p % ((long)H * W);
+  const int b = p / ((long)H * W);
+  dst[idx] = from_f32<T>(c < C ? src[((long)b * C + c) * H * W + hw] : 0.f);
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int B, int C,
+                                    int H, int W, int ld) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * C * H * W;
+  if (idx >= total) return;
+  const long hw = idx % ((long)H * W);
+  const int c = (idx / ((long)H * W)) % C;
+  const int b = idx / ((long)H * W * C);
+  dst[idx] = to_f32(src[((long)b * H * W + hw) * ld + c]);
+}
+
+// ------------------------------------------------------------------ BatchNorm statistics
+// partials: [nparts][2][C] (sum, sum of squares).  One workgroup per 4 channels.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(
+    const float* __restrict__ partials, int nparts, int C, double count, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, float momentum, float* running_mean, float* running_var,
+    float* __restrict__ mean_out, float* __restrict__ invstd_out, float* __restrict__ scale_out,
+    float* __restrict__ shift_out) {
+  __shared__ double red[2][64][4];
+  const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;
+  const int c = blockIdx.x * 4 + cl;
+  double s = 0.0, q = 0.0;
+  if (c < C)
+    for (int r = rl; r < nparts; r += 64) {
+      s += (double)partials[((long)r * 2) * C + c];
+      q += (double)partials[((long)r * 2 + 1) * C + c];
+    }
+  red[0][rl][cl] = s;
+  red[1][rl][cl] = q;
+  __syncthreads();
+  if (threadIdx.x < 4 && blockIdx.x * 4 + threadIdx.x < C) {
+    const int cc = blockIdx.x * 4 + threadIdx.x;
+    double ss = 0.0, qq = 0.0;
+    for (int r = 0; r < 64; ++r) {
+      ss += red[0][r][threadIdx.x];
+      qq += red[1][r][threadIdx.x];
+    }
+    const double mean = ss / count;
+    double var = qq / count - mean * mean;   // biased (normalisation) variance
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[cc] : 1.f, bt = beta ? beta[cc] : 0.f;
+    mean_out[cc] = (float)mean;
+    invstd_out[cc] = invstd;
+    scale_out[cc] = g * invstd;
+    shift_out[cc] = bt - (float)mean * g * invstd;
+    if (running_mean != nullptr) {
+      // nn.BatchNorm2d: running = (1-m)*running + m*batch, with the UNBIASED batch variance
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[cc] = (1.f - momentum) * running_mean[cc] + momentum * (float)mean;
+      running_var[cc] = (1.f - momentum) * running_var[cc] + momentum * (float)unbiased;
+    }
+  }
+}
+
+__global__ void bn_fold_eval_kernel(const float* gamma, const float* beta, const float* rmean,
+                                    const float* rvar, float eps, const float* conv_bias, float* scale,
+                                    float* shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.f / sqrtf(rvar[c] + eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float sc = g * invstd;
+  scale[c] = sc;
+  shift[c] = b + ((conv_bias ? conv_bias[c] : 0.f) - rmean[c]) * sc;
+}
+
+// ------------------------------------------------------------------ BN + ReLU (+mask)(+pool) forward
+// One thread per (2x2 pixel quad, 16-byte channel group).
+template <typename T>
+__global__ void bn_act_fwd_kernel(const T* __restrict__ y, T* __restrict__ a, T* __restrict__ pooled, int B,
+                                  int H, int W, int C, const float* __restrict__ scale,
+                                  const float* __restrict__ shift, const float* __restrict__ keep,
+                                  int relu) {
+  constexpr int E = Vec16<T>::N;
+  const int CG = C / E;
+  const int QH = (H + 1) >> 1, QW = (W + 1) >> 1;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * QH * QW * CG;
+  if (idx >= total) return;
+  const int cg = idx % CG;
+  long t = idx / CG;
+  const int qx = t % QW;
+  t /= QW;
+  const int qy = t % QH;
+  const int b = t / QH;
+  const int c0 = cg * E;
+  float sc[E], sh[E], kp[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    sc[e] = scale ? scale[c0 + e] : 1.f;
+    sh[e] = shift ? shift[c0 + e] : 0.f;
+    kp[e] = keep ? keep[(long)b * C + c0 + e] : 1.f;
+  }
+  float mx[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) mx[e] = -INFINITY;
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      const int yy = 2 * qy + dy, xx = 2 * qx + dx;
+      if (yy < H && xx < W) {
+        const long off = (((long)b * H + yy) * W + xx) * C + c0;
+        Vec16<T> v = load16(y + off);
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          float z = to_f32(v.v[e]) * sc[e] + sh[e];
+          if (relu) z = fmaxf(z, 0.f);
+          z *= kp[e];
+          o.v[e] = from_f32<T>(z);
+          mx[e] = fmaxf(mx[e], to_f32(o.v[e]));
+        }
+        if (a != nullptr) store16(a + off, o);
+      }
+    }
+  if (pooled != nullptr && 2 * qy + 1 < H && 2 * qx + 1 < W) {
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < E; ++e) o.v[e] = from_f32<T>(mx[e]);
+    store16(pooled + (((long)b * (H >> 1) + qy) * (W >> 1) + qx) * C + c0, o);
+  }
+}
+
+// ------------------------------------------------------------------ per-channel reductions
+// Generic NHWC reducer: workgroup k covers pixels [k*chunk, (k+1)*chunk); threads are laid out as
+// (pixel lane, channel group).  MODE 0: BatchNorm backward sums (sum dz, sum dz*xhat).
+// MODE 1: 1x1-conv weight gradient (sum d*x, sum d) with a per-pixel scalar d (fp32).
+struct RedArgs {
+  const void* x;        // MODE 0: conv output y ; MODE 1: input activations
+  const void* g;        // MODE 0: grad wrt activation (T) ; MODE 1: per-pixel scalar (float)
+  const float* scale;   // MODE 0
+  const float* shift;
+  const float* mean;
+  const float* invstd;
+  const float* keep;    // [B][C] or null
+  float* partials;      // [nblk][2][C]
+  long npix, hw;
+  int C, ldx, ldg, chunk, relu;
+};
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(RED_THREADS) void channel_reduce_kernel(RedArgs a) {
+  constexpr int E = Vec16<T>::N;
+  __shared__ float red[2][RED_THREADS * E];
+  const int CG = a.C / E;
+  const int lanes = RED_THREADS / CG;
+  const int tid = threadIdx.x;
+  const int cg = tid % CG, pl = tid / CG;
+  const int c0 = cg * E;
+  float s0[E], s1[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) s0[e] = s1[e] = 0.f;
+  if (pl < lanes) {
+    float sc[E], sh[E], mu[E], is[E];
+    if (MODE == 0) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        sc[e] = a.scale[c0 + e];
+        sh[e] = a.shift[c0 + e];
+        mu[e] = a.mean[c0 + e];
+        is[e] = a.invstd[c0 + e];
+      }
+    }
+    const long pbeg = (long)blockIdx.x * a.chunk;
+    long pend = pbeg + a.chunk;
+    if (pend > a.npix) pend = a.npix;
+    const T* x = reinterpret_cast<const T*>(a.x);
+    for (long p = pbeg + pl; p < pend; p += lanes) {
+      Vec16<T> xv = load16(x + p * a.ldx + c0);
+      if (MODE == 0) {
+        Vec16<T> gv = load16(reinterpret_cast<const T*>(a.g) + p * a.ldg + c0);
+        const int b = p / a.hw;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const float yv = to_f32(xv.v[e]);
+          float dz = to_f32(gv.v[e]);
+          if (a.keep) dz *= a.keep[(long)b * a.C + c0 + e];
+          if (a.relu && !(yv * sc[e] + sh[e] > 0.f)) dz = 0.f;
+          s0[e] += dz;
+          s1[e] += dz * ((yv - mu[e]) * is[e]);
+        }
+      } else {
+        const float d = reinterpret_cast<const float*>(a.g)[p];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          s0[e] += d * to_f32(xv.v[e]);
+          s1[e] += d;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    red[0][tid * E + e] = s0[e];
+    red[1][tid * E + e] = s1[e];
+  }
+  __syncthreads();
+  for (int c = tid; c < a.C; c += RED_THREADS) {
+    const int g = c / E, e = c - g * E;
+    float t0 = 0.f, t1 = 0.f;
+    for (int l = 0; l < lanes; ++l) {
+      t0 += red[0][(l * CG + g) * E + e];
+      t1 += red[1][(l * CG + g) * E + e];
+    }
+    a.partials[((long)blockIdx.x * 2) * a.C + c] = t0;
+    a.partials[((long)blockIdx.x * 2 + 1) * a.C + c] = t1;
+  }
+}
+
+// sums [nparts][2][C] partials into out0[C], out1[C] (fp32), optionally accumulating
+__global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restrict__ partials, int nparts,
+                                                          int ldp, int C, float* out0, float* out1,
+                                                          int accumulate) {
+  __shared__ double red[2][64][4];
+  const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;
+  const int c = blockIdx.x * 4 + cl;
+  double s = 0.0, q = 0.0;
+  if (c < C)
+    for (int r = rl; r < nparts; r += 64) {
+      s += (double)partials[((long)r * 2) * ldp + c];
+      q += (double)partials[((long)r * 2 + 1) * ldp + c];
+    }
+  red[0][rl][cl] = s;
+  red[1][rl][cl] = q;
+  __syncthreads();
+  if (threadIdx.x < 4 && blockIdx.x * 4 + threadIdx.x < C) {
+    const int cc = blockIdx.x * 4 + threadIdx.x;
+    double ss = 0.0, qq = 0.0;
+    for (int r = 0; r < 64; ++r) {
+      ss += red[0][r][threadIdx.x];
+      qq += red[1][r][threadIdx.x];
+    }
+    if (out0) out0[cc] = accumulate ? out0[cc] + (float)ss : (float)ss;
+    if (out1) out1[cc] = accumulate ? out1[cc] + (float)qq : (float)qq;
+  }
+}
+
+// dy = scale * (dz - sum_dz/n - xhat * sum_dzxhat/n)
+template <typename T>
+__global__ void bn_act_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ y, T* __restrict__ dy,
+                                        long npix, long hw, int C, const float* __restrict__ scale,
+                                        const float* __restrict__ shift, const float* __restrict__ mean,
+                                        const float* __restrict__ invstd, const float* __restrict__ keep,
+                                        const float* __restrict__ sum_dz, const float* __restrict__ sum_dzx,
+                                        float inv_n, int relu) {
+  constexpr int E = Vec16<T>::N;
+  const int CG = C / E;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= npix * CG) return;
+  const int cg = idx % CG;
+  const long p = idx / CG;
+  const int c0 = cg * E;
+  const int b = p / hw;
+  Vec16<T> gv = load16(g + p * C + c0);
+  Vec16<T> yv = load16(y + p * C + c0);
+  Vec16<T> o;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int c = c0 + e;
+    const float yy = to_f32(yv.v[e]);
+    float dz = to_f32(gv.v[e]);
+    if (keep) dz *= keep[(long)b * C + c];
+    if (relu && !(yy * scale[c] + shift[c] > 0.f)) dz = 0.f;
+    const float xh = (yy - mean[c]) * invstd[c];
+    o.v[e] = from_f32<T>(scale[c] * (dz - sum_dz[c] * inv_n - xh * sum_dzx[c] * inv_n));
+  }
+  store16(dy + p * C + c0, o);
+}
+
+// ------------------------------------------------------------------ 2x2 max-pool backward (+ skip grad)
+// da[pix] = dskip[pix] + (pix is the first maximum of its quad ? dpooled[quad] : 0)
+template <typename T>
+__global__ void pool_bwd_kernel(const T* __restrict__ a, const T* __restrict__ dpooled,
+                                const T* __restrict__ dskip, int ldskip, T* __restrict__ da, int B, int H,
+                                int W, int C) {
+  constexpr int E = Vec16<T>::N;
+  const int CG = C / E;
+  const int QH = (H + 1) >> 1, QW = (W + 1) >> 1;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)B * QH * QW * CG) return;
+  const int cg = idx % CG;
+  long t = idx / CG;
+  const int qx = t % QW;
+  t /= QW;
+  const int qy = t % QH;
+  const int b = t / QH;
+  const int c0 = cg * E;
+  const bool full = (2 * qy + 1 < H) && (2 * qx + 1 < W);
+  Vec16<T> av[4];
+  int arg[E];
+  float dp[E];
+  if (full) {
+    float mx[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      mx[e] = -INFINITY;
+      arg[e] = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int yy = 2 * qy + (k >> 1), xx = 2 * qx + (k & 1);
+      av[k] = load16(a + (((long)b * H + yy) * W + xx) * C + c0);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const float v = to_f32(av[k].v[e]);
+        if (v > mx[e] || k == 0) {   // strict '>' keeps the first maximum in scan order
+          mx[e] = v;
+          arg[e] = k;
+        }
+      }
+    }
+    Vec16<T> d = load16(dpooled + (((long)b * (H >> 1) + qy) * (W >> 1) + qx) * C + c0);
+#pragma unroll
+    for (int e = 0; e < E; ++e) dp[e] = to_f32(d.v[e]);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int yy = 2 * qy + (k >> 1), xx = 2 * qx + (k & 1);
+    if (yy < H && xx < W) {
+      const long pix = ((long)b * H + yy) * W + xx;
+      Vec16<T> o;
+      Vec16<T> sk = zero16<T>();
+      if (dskip) sk = load16(dskip + pix * ldskip + c0);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        float v = dskip ? to_f32(sk.v[e]) : 0.f;
+        if (full && arg[e] == k) v += dp[e];
+        o.v[e] = from_f32<T>(v);
+      }
+      store16(da + pix * C + c0, o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ bilinear resize (align_corners=False)
+__device__ __forceinline__ void src_index(float scale, int dst, int in_size, int& i0, int& i1, float& l1) {
+  float s = scale * ((float)dst + 0.5f) - 0.5f;
+  if (s < 0.f) s = 0.f;
+  i0 = (int)s;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+  l1 = s - (float)i0;
+}
+
+// out[b,y,x, 0:C1] = resize(low)[b,y,x,:], out[b,y,x, C1:C1+C2] = skip[b,y,x,:]
+template <typename T>
+__global__ void upsample_concat_kernel(const T* __restrict__ low, int h, int w, int C1,
+                                       const T* __restrict__ skip, int ldskip, int C2, T* __restrict__ out,
+                                       int B, int H, int W, float sy, float sx) {
+  constexpr int E = Vec16<T>::N;
+  const int C = C1 + C2, CG = C / E, CG1 = C1 / E;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)B * H * W * CG) return;
+  const int cg = idx % CG;
+  long p = idx / CG;
+  const int x = p % W;
+  const int y = (p / W) % H;
+  const int b = p / ((long)W * H);
+  Vec16<T> o;
+  if (cg < CG1) {
+    int y0, y1, x0, x1;
+    float ly, lx;
+    src_index(sy, y, h, y0, y1, ly);
+    src_index(sx, x, w, x0, x1, lx);
+    const int c0 = cg * E;
+    const T* base = low + (long)b * h * w * C1 + c0;
+    Vec16<T> v00 = load16(base + ((long)y0 * w + x0) * C1);
+    Vec16<T> v01 = load16(base + ((long)y0 * w + x1) * C1);
+    Vec16<T> v10 = load16(base + ((long)y1 * w + x0) * C1);
+    Vec16<T> v11 = load16(base + ((long)y1 * w + x1) * C1);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      o.v[e] = from_f32<T>(hy * (hx * to_f32(v00.v[e]) + lx * to_f32(v01.v[e])) +
+                           ly * (hx * to_f32(v10.v[e]) + lx * to_f32(v11.v[e])));
+  } else {
+    o = load16(skip + p * ldskip + (cg - CG1) * E);
+  }
+  store16(out + p * C + cg * E, o);
+}
+
+// dlow[b,i,j,:] = sum over output pixels (y,x) that read (i,j) of wy*wx*dout[b,y,x,:] (gather form)
+template <typename T>
+__global__ void upsample_bwd_kernel(const T* __restrict__ dout, int ldout, int H, int W, T* __restrict__ dlow,
+                                    int B, int h, int w, int C1, float sy, float sx) {
+  constexpr int E = Vec16<T>::N;
+  const int CG = C1 / E;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)B * h * w * CG) return;
+  const int cg = idx % CG;
+  long p = idx / CG;
+  const int j = p % w;
+  const int i = (p / w) % h;
+  const int b = p / ((long)w * h);
+  float acc[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) acc[e] = 0.f;
+  int ylo = (int)floorf(((float)i - 0.5f) / sy - 0.5f) - 1;
+  int yhi = (int)ceilf(((float)i + 1.5f) / sy - 0.5f) + 1;
+  int xlo = (int)floorf(((float)j - 0.5f) / sx - 0.5f) - 1;
+  int xhi = (int)ceilf(((float)j + 1.5f) / sx - 0.5f) + 1;
+  if (ylo < 0) ylo = 0;
+  if (xlo < 0) xlo = 0;
+  if (yhi > H - 1) yhi = H - 1;
+  if (xhi > W - 1) xhi = W - 1;
+  for (int y = ylo; y <= yhi; ++y) {
+    int y0, y1;
+    float ly;
+    src_index(sy, y, h, y0, y1, ly);
+    const float wy = (y0 == i ? 1.f - ly : 0.f) + (y1 == i ? ly : 0.f);
+    if (wy == 0.f) continue;
+    for (int x = xlo; x <= xhi; ++x) {
+      int x0, x1;
+      float lx;
+      src_index(sx, x, w, x0, x1, lx);
+      const float wx = (x0 == j ? 1.f - lx : 0.f) + (x1 == j ? lx : 0.f);
+      if (wx == 0.f) continue;
+      Vec16<T> v = load16(dout + (((long)b * H + y) * W + x) * ldout + cg * E);
+      const float wgt = wy * wx;
+#pragma unroll
+      for (int e = 0; e < E; ++e) acc[e] += wgt * to_f32(v.v[e]);
+    }
+  }
+  Vec16<T> o;
+#pragma unroll
+  for (int e = 0; e < E; ++e) o.v[e] = from_f32<T>(acc[e]);
+  store16(dlow + p * C1 + cg * E, o);
+}
+
+// ------------------------------------------------------------------ final 1x1 convolution (few outputs)
+// out[b,o,hw] = bias[o] + sum_c x[b,hw,c] * w[o,c]      (out is NCHW fp32)
+template <typename T>
+__global__ __launch_bounds__(256) void head1x1_fwd_kernel(const T* __restrict__ x, int ldx,
+                                                          const float* __restrict__ w,
+                                                          const float* __restrict__ bias,
+                                                          float* __restrict__ out, long npix, long hw, int C,
+                                                          int Co) {
+  constexpr int E = Vec16<T>::N;
+  extern __shared__ float wl[];   // [Co][C]
+  for (int i = threadIdx.x; i < Co * C; i += blockDim.x) wl[i] = w[i];
+  __syncthreads();
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npix) return;
+  const int b = p / hw;
+  const long r = p - (long)b * hw;
+  for (int o = 0; o < Co; ++o) {
+    float s = bias ? bias[o] : 0.f;
+    for (int c0 = 0; c0 < C; c0 += E) {
+      Vec16<T> v = load16(x + p * ldx + c0);
+#pragma unroll
+      for (int e = 0; e < E; ++e) s += to_f32(v.v[e]) * wl[o * C + c0 + e];
+    }
+    out[((long)b * Co + o) * hw + r] = s;
+  }
+}
+
+// dx[b,hw,c] = sum_o dout[b,o,hw] * w[o,c]
+template <typename T>
+__global__ void head1x1_bwd_data_kernel(const float* __restrict__ dout, const float* __restrict__ w,
+                                        T* __restrict__ dx, long npix, long hw, int C, int Co) {
+  constexpr int E = Vec16<T>::N;
+  const int CG = C / E;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= npix * CG) return;
+  const int cg = idx % CG;
+  const long p = idx / CG;
+  const int b = p / hw;
+  const long r = p - (long)b * hw;
+  float acc[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) acc[e] = 0.f;
+  for (int o = 0; o < Co; ++o) {
+    const float d = dout[((long)b * Co + o) * hw + r];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] += d * w[o * C + cg * E + e];
+  }
+  Vec16<T> ov;
+#pragma unroll
+  for (int e = 0; e < E; ++e) ov.v[e] = from_f32<T>(acc[e]);
+  store16(dx + p * C + cg * E, ov);
+}
+
+inline int reduce_blocks(long npix) {
+  long n = (npix + 127) / 128;
+  if (n > 1024) n = 1024;
+  if (n < 1) n = 1;
+  return (int)n;
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, ...)                       \
+  do {                                               \
+    if ((dtype) == UNETK_BF16) {                     \
+      using T = bf16;                                \
+      __VA_ARGS__;                                   \
+    } else {                                         \
+      using T = float;                               \
+      __VA_ARGS__;                                   \
+    }                                                \
+  } while (0)
+
+#define CHECK_DTYPE(name, dtype) \
+  UNETK_CHECK_ARG((dtype) == UNETK_F32 || (dtype) == UNETK_BF16, name ": bad dtype %d", (dtype))
+#define CHECK_VEC(name, dtype, C) \
+  UNETK_CHECK_ARG((C) % ((dtype) == UNETK_BF16 ? 8 : 4) == 0, name ": channel count %d not a multiple of %d", (C), ((dtype) == UNETK_BF16 ? 8 : 4))
+
+extern "C" {
+
+int unetk_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int ld, int dtype,
+                       hipStream_t stream) {
+  UNETK_CHECK_ARG(src && dst && ld >= C, "nchw_to_nhwc: bad arguments");
+  CHECK_DTYPE("nchw_to_nhwc", dtype);
+  const long total = (long)B * H * W * ld;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(cdiv(total, 256)), dim3(256), 0, stream,
+                                       src, (T*)dst, B, C, H, W, ld));
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_nhwc_to_nchw(const void* src, int ld, float* dst, int B, int C, int H, int W, int dtype,
+                       hipStream_t stream) {
+  UNETK_CHECK_ARG(src && dst && ld >= C, "nhwc_to_nchw: bad arguments");
+  CHECK_DTYPE("nhwc_to_nchw", dtype);
+  const long total = (long)B * H * W * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, dim3(cdiv(total, 256)), dim3(256), 0, stream,
+                                       (const T*)src, dst, B, C, H, W, ld));
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_bn_finalize(const float* partials, int nparts, int C, int64_t count, const float* gamma,
+                      const float* beta, float eps, float momentum, float* running_mean,
+                      float* running_var, float* mean, float* invstd, float* scale, float* shift,
+                      hipStream_t stream) {
+  UNETK_CHECK_ARG(partials && mean && invstd && scale && shift && nparts > 0 && C > 0 && count > 0,
+                  "bn_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, partials, nparts, C,
+                     (double)count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
+                     scale, shift);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, const float* conv_bias, float* scale,
+                       float* shift, int C, hipStream_t stream) {
+  UNETK_CHECK_ARG(running_mean && running_var && scale && shift && C > 0, "bn_fold_eval: bad arguments");
+  hipLaunchKernelGGL(bn_fold_eval_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, gamma, beta,
+                     running_mean, running_var, eps, conv_bias, scale, shift, C);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_bn_act_fwd(const void* y, void* a, void* pooled, int B, int H, int W, int C, const float* scale,
+                     const float* shift, const float* keep, int relu, int dtype, hipStream_t stream) {
+  UNETK_CHECK_ARG(y && (a || pooled), "bn_act_fwd: null pointer");
+  CHECK_DTYPE("bn_act_fwd", dtype);
+  CHECK_VEC("bn_act_fwd", dtype, C);
+  const int E = dtype == UNETK_BF16 ? 8 : 4;
+  const long total = (long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / E);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3(cdiv(total, 256)), dim3(256), 0, stream,
+                                       (const T*)y, (T*)a, (T*)pooled, B, H, W, C, scale, shift, keep, relu));
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_reduce_num_partials(int64_t npix) { return reduce_blocks(npix); }
+
+int unetk_bn_act_bwd(const void* g, const void* y, void* dy, int B, int H, int W, int C,
+                     const float* scale, const float* shift, const float* mean, const float* invstd,
+                     const float* keep, int relu, float* dgamma, float* dbeta, int accumulate,
+                     float* partials, float* sums, int dtype, hipStream_t stream) {
+  UNETK_CHECK_ARG(g && y && dy && scale && shift && mean && invstd && partials && sums,
+                  "bn_act_bwd: null pointer");
+  CHECK_DTYPE("bn_act_bwd", dtype);
+  CHECK_VEC("bn_act_bwd", dtype, C);
+  const int E = dtype == UNETK_BF16 ? 8 : 4;
+  UNETK_CHECK_ARG(C / E <= RED_THREADS, "bn_act_bwd: too many channels (%d)", C);
+  const long npix = (long)B * H * W;
+  const int nblk = reduce_blocks(npix);
+  RedArgs r;
+  r.x = y; r.g = g; r.scale = scale; r.shift = shift; r.mean = mean; r.invstd = invstd; r.keep = keep;
+  r.partials = partials; r.npix = npix; r.hw = (long)H * W; r.C = C; r.ldx = C; r.ldg = C;
+  r.chunk = cdiv(npix, nblk); r.relu = relu;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((channel_reduce_kernel<T, 0>), dim3(nblk), dim3(RED_THREADS), 0,
+                                       stream, r));
+  UNETK_CHECK_LAUNCH();
+  // sums[0:C] = sum dz (= dbeta), sums[C:2C] = sum dz*xhat (= dgamma)
+  hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, partials, nblk, C, C, sums,
+                     sums + C, 0);
+  UNETK_CHECK_LAUNCH();
+  if (dbeta || dgamma) {
+    hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, partials, nblk, C, C, dbeta,
+                       dgamma, accumulate);
+    UNETK_CHECK_LAUNCH();
+  }
+  const long total = npix * (C / E);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_bwd_apply_kernel<T>, dim3(cdiv(total, 256)), dim3(256), 0,
+                                       stream, (const T*)g, (const T*)y, (T*)dy, npix, (long)H * W, C, scale,
+                                       shift, mean, invstd, keep, sums, sums + C, 1.0f / (float)npix, relu));
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_pool_bwd(const void* a, const void* dpooled, const void* dskip, int ldskip, void* da, int B,
+                   int H, int W, int C, int dtype, hipStream_t stream) {
+  UNETK_CHECK_ARG(a && dpooled && da, "pool_bwd: null pointer");
+  CHECK_DTYPE("pool_bwd", dtype);
+  CHECK_VEC("pool_bwd", dtype, C);
+  const int E = dtype == UNETK_BF16 ? 8 : 4;
+  UNETK_CHECK_ARG(dskip == nullptr || ldskip % E == 0, "pool_bwd: skip stride misaligned");
+  const long total = (long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / E);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(pool_bwd_kernel<T>, dim3(cdiv(total, 256)), dim3(256), 0, stream,
+                                       (const T*)a, (const T*)dpooled, (const T*)dskip, ldskip, (T*)da, B, H,
+                                       W, C));
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_upsample_concat_fwd(const void* low, int h, int w, int C1, const void* skip, int ldskip, int C2,
+                              void* out, int B, int H, int W, int dtype, hipStream_t stream) {
+  UNETK_CHECK_ARG(low && out && (skip || C2 == 0), "upsample_concat_fwd: null pointer");
+  CHECK_DTYPE("upsample_concat_fwd", dtype);
+  CHECK_VEC("upsample_concat_fwd", dtype, C1);
+  CHECK_VEC("upsample_concat_fwd", dtype, C2);
+  const int E = dtype == UNETK_BF16 ? 8 : 4;
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  const long total = (long)B * H * W * ((C1 + C2) / E);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(upsample_concat_kernel<T>, dim3(cdiv(total, 256)), dim3(256), 0,
+                                       stream, (const T*)low, h, w, C1, (const T*)skip, ldskip, C2, (T*)out,
+                                       B, H, W, sy, sx));
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_upsample_bwd(const void* dout, int ldout, int H, int W, void* dlow, int B, int h, int w, int C1,
+                       int dtype, hipStream_t stream) {
+  UNETK_CHECK_ARG(dout && dlow, "upsample_bwd: null pointer");
+  CHECK_DTYPE("upsample_bwd", dtype);
+  CHECK_VEC("upsample_bwd", dtype, C1);
+  const int E = dtype == UNETK_BF16 ? 8 : 4;
+  UNETK_CHECK_ARG(ldout % E == 0, "upsample_bwd: stride misaligned");
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  const long total = (long)B * h * w * (C1 / E);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(upsample_bwd_kernel<T>, dim3(cdiv(total, 256)), dim3(256), 0, stream,
+                                       (const T*)dout, ldout, H, W, (T*)dlow, B, h, w, C1, sy, sx));
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_head1x1_fwd(const void* x, int ldx, const float* w, const float* bias, float* out, int B, int H,
+                      int W, int C, int Co, int dtype, hipStream_t stream) {
+  UNETK_CHECK_ARG(x && w && out, "head1x1_fwd: null pointer");
+  CHECK_DTYPE("head1x1_fwd", dtype);
+  CHECK_VEC("head1x1_fwd", dtype, C);
+  UNETK_CHECK_ARG((long)Co * C * 4 <= 48 * 1024, "head1x1_fwd: weight (%d x %d) too large", Co, C);
+  const long npix = (long)B * H * W;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(head1x1_fwd_kernel<T>, dim3(cdiv(npix, 256)), dim3(256),
+                                       (size_t)Co * C * 4, stream, (const T*)x, ldx, w, bias, out, npix,
+                                       (long)H * W, C, Co));
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_head1x1_bwd(const void* x, int ldx, const float* w, const float* dout, void* dx, float* dw,
+                      float* db, int B, int H, int W, int C, int Co, int accumulate, float* partials,
+                      int dtype, hipStream_t stream) {
+  UNETK_CHECK_ARG(x && w && dout && partials, "head1x1_bwd: null pointer");
+  CHECK_DTYPE("head1x1_bwd", dtype);
+  CHECK_VEC("head1x1_bwd", dtype, C);
+  UNETK_CHECK_ARG(!(dw || db) || B == 1 || Co == 1,
+                  "head1x1_bwd: weight gradient supports Co == 1 (or B == 1) per call");
+  const int E = dtype == UNETK_BF16 ? 8 : 4;
+  const long npix = (long)B * H * W;
+  if (dx) {
+    const long total = npix * (C / E);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(head1x1_bwd_data_kernel<T>, dim3(cdiv(total, 256)), dim3(256), 0,
+                                         stream, dout, w, (T*)dx, npix, (long)H * W, C, Co));
+    UNETK_CHECK_LAUNCH();
+  }
+  if (dw || db) {
+    const int nblk = reduce_blocks(npix);
+    for (int o = 0; o < Co; ++o) {
+      RedArgs r;
+      r.x = x; r.g = dout + (long)o * H * W; r.scale = r.shift = r.mean = r.invstd = r.keep = nullptr;
+      r.partials = partials; r.npix = npix; r.hw = (long)H * W; r.C = C; r.ldx = ldx; r.ldg = 1;
+      r.chunk = cdiv(npix, nblk); r.relu = 0;
+      DISPATCH_T(dtype, hipLaunchKernelGGL((channel_reduce_kernel<T, 1>), dim3(nblk), dim3(RED_THREADS), 0,
+                                           stream, r));
+      UNETK_CHECK_LAUNCH();
+      // out0 = sum d*x per channel -> dw[o][:]; out1 (same value in every channel) -> db[o] via channel 0
+      hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, partials, nblk, C, C,
+                         dw ? dw + (long)o * C : nullptr, (float*)nullptr, accumulate);
+      UNETK_CHECK_LAUNCH();
+      if (db) {
+        hipLaunchKernelGGL(partial_sum_kernel, dim3(1), dim3(256), 0, stream, partials, nblk, C, 1,
+                           (float*)nullptr, db + o, accumulate);
+        UNETK_CHECK_LAUNCH();
+      }
+    }
+  }
+  return UNETK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,241 @@
+"""Tensor-level wrappers over the libunetk C ABI.
+
+Activations are NHWC tensors of the compute dtype (float32 or bfloat16) living on the
+GPU; torch only provides their memory and the current stream.  Every function
+enqueues kernels on ``torch.cuda.current_stream()`` and returns without synchronising.
+"""
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream, dtype_code
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def _vec(dt):
+    return 8 if dt == torch.bfloat16 else 4
+
+
+def pad_channels(c: int, dt) -> int:
+    v = _vec(dt)
+    return (c + v - 1) // v * v
+
+
+def _require_cuda(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"unet_amd: {what} must live on the GPU; this package drives hand-written gfx950 "
+            "kernels and has no CPU fallback")
+
+
+def nchw_to_nhwc(x: torch.Tensor, dt, ld: Optional[int] = None) -> torch.Tensor:
+    """fp32 (B,C,H,W) -> compute-dtype (B,H,W,ld), zero-filled channel padding."""
+    _require_cuda(x, "input")
+    x = x.contiguous().float()
+    B, C, H, W = x.shape
+    ld = ld or pad_channels(C, dt)
+    out = torch.empty((B, H, W, ld), dtype=dt, device=x.device)
+    call("unetk_nchw_to_nhwc", ptr(x), ptr(out), B, C, H, W, ld, dtype_code(dt), stream())
+    return out
+
+
+def nhwc_to_nchw(x: torch.Tensor, C: int) -> torch.Tensor:
+    B, H, W, ld = x.shape
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+    call("unetk_nhwc_to_nchw", ptr(x), ld, ptr(out), B, C, H, W, dtype_code(x.dtype), stream())
+    return out
+
+
+class PackedConv:
+    """A convolution weight re-packed for the implicit-GEMM kernel."""
+    __slots__ = ("data", "Co", "Ci", "ks", "bn", "dt")
+
+    def __init__(self, w: torch.Tensor, dt, transpose: bool = False, ci_pad: Optional[int] = None):
+        """w: fp32 (Co, Ci, k, k) or (Co, Ci) on the GPU.  transpose packs the data-gradient conv."""
+        _require_cuda(w, "weight")
+        if w.dim() == 2:
+            w = w.view(w.shape[0], w.shape[1], 1, 1)
+        w = w.detach().contiguous().float()
+        Co, Ci, ks, _ = w.shape
+        lib = _lib.load()
+        pCo, pCi = (Ci, Co) if transpose else (Co, Ci)
+        self.bn = lib.unetk_conv_pick_bn(pCo)
+        self.Co, self.Ci, self.ks, self.dt = pCo, pCi, ks, dt
+        n = lib.unetk_conv_packed_elems(pCo, pCi, ks, self.bn, dtype_code(dt))
+        self.data = torch.empty(n, dtype=dt, device=w.device)
+        call("unetk_conv_pack_weight", ptr(w), ptr(self.data), Co, Ci, ks, self.bn, dtype_code(dt),
+             1 if transpose else 0, stream())
+
+
+def conv_fwd(x: torch.Tensor, pw: PackedConv, Ci: Optional[int] = None, Co: Optional[int] = None,
+             out: Optional[torch.Tensor] = None, want_stats: bool = False, scale=None, shift=None,
+             act: int = 0, resid=None, resid_keep=None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """x: (B,H,W,ld) NHWC.  Channel counts default to the packed weight's, rounded up to the
+    vector width for the output (padding channels come out as exact zeros)."""
+    B, H, W, ldin = x.shape
+    dt = x.dtype
+    v = _vec(dt)
+    Ci = Ci if Ci is not None else min(ldin, pad_channels(pw.Ci, dt))
+    Co = Co if Co is not None else pad_channels(pw.Co, dt)
+    if out is None:
+        out = torch.empty((B, H, W, Co), dtype=dt, device=x.device)
+    ldout = out.shape[-1]
+    stats = None
+    if want_stats:
+        nt = _lib.load().unetk_conv_num_tiles(B, H, W, pw.ks)
+        stats = torch.empty((nt, 2, Co), dtype=torch.float32, device=x.device)
+    call("unetk_conv_fwd", ptr(x), ldin, ptr(pw.data), ptr(out), ldout, B, H, W, Ci, Co, pw.ks, pw.bn,
+         dtype_code(dt), ptr(stats), ptr(scale), ptr(shift), act, ptr(resid),
+         resid.shape[-1] if resid is not None else 0, ptr(resid_keep), stream())
+    return out, stats
+
+
+def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, Ci: int, Co: int, ks: int,
+               dw: Optional[torch.Tensor] = None, accumulate: bool = False,
+               workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dw (Co,Ci,k,k) fp32 from NHWC activations x (B,H,W,ldx) and output gradient dy (B,H,W,lddy)."""
+    B, H, W, ldx = x.shape
+    dt = x.dtype
+    v = _vec(dt)
+    Cip, Cop = pad_channels(Ci, dt), pad_channels(Co, dt)
+    need = _lib.load().unetk_conv_wgrad_workspace_bytes(B, H, W, Cip, Cop, ks, dtype_code(dt))
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
+    padded = (Cip != Ci) or (Cop != Co)
+    tgt = dw
+    if dw is None or padded:
+        tgt = torch.empty((Cop, Cip, ks, ks), dtype=torch.float32, device=x.device)
+    call("unetk_conv_wgrad", ptr(x), ldx, ptr(dy), dy.shape[-1], ptr(tgt), B, H, W, Cip, Cop, ks,
+         dtype_code(dt), ptr(workspace), workspace.numel() * workspace.element_size(),
+         1 if (accumulate and not padded and dw is not None) else 0, stream())
+    if padded:
+        res = tgt[:Co, :Ci]
+        if dw is not None:
+            if accumulate:
+                dw += res
+            else:
+                dw.copy_(res)
+            return dw
+        return res.contiguous()
+    return tgt
+
+
+def bn_finalize(stats, count, gamma, beta, running_mean=None, running_var=None,
+                eps=BN_EPS, momentum=BN_MOMENTUM):
+    """Per-tile partial sums -> (mean, invstd, scale, shift); updates the running stats in place."""
+    nparts, _, C = stats.shape
+    dev = stats.device
+    out = torch.empty((4, C), dtype=torch.float32, device=dev)
+    call("unetk_bn_finalize", ptr(stats), nparts, C, count, ptr(gamma), ptr(beta), eps, momentum,
+         ptr(running_mean), ptr(running_var), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), stream())
+    return out[0], out[1], out[2], out[3]
+
+
+def bn_fold_eval(gamma, beta, running_mean, running_var, conv_bias=None, eps=BN_EPS):
+    C = running_mean.numel()
+    out = torch.empty((2, C), dtype=torch.float32, device=running_mean.device)
+    call("unetk_bn_fold_eval", ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), eps,
+         ptr(conv_bias), ptr(out[0]), ptr(out[1]), C, stream())
+    return out[0], out[1]
+
+
+def bn_act_fwd(y, scale, shift, keep=None, relu=True, pool=False, write_a=True):
+    B, H, W, C = y.shape
+    a = torch.empty_like(y) if write_a else None
+    pooled = torch.empty((B, H // 2, W // 2, C), dtype=y.dtype, device=y.device) if pool else None
+    call("unetk_bn_act_fwd", ptr(y), ptr(a), ptr(pooled), B, H, W, C, ptr(scale), ptr(shift), ptr(keep),
+         1 if relu else 0, dtype_code(y.dtype), stream())
+    return a, pooled
+
+
+def maxpool2x2(a):
+    return bn_act_fwd(a, None, None, None, relu=False, pool=True, write_a=False)[1]
+
+
+def bn_act_bwd(g, y, scale, shift, mean, invstd, keep=None, relu=True, dgamma=None, dbeta=None,
+               accumulate=False):
+    """Returns (dy, dgamma, dbeta)."""
+    B, H, W, C = y.shape
+    dev = y.device
+    dy = torch.empty_like(y)
+    nparts = _lib.load().unetk_reduce_num_partials(B * H * W)
+    partials = torch.empty((nparts, 2, C), dtype=torch.float32, device=dev)
+    sums = torch.empty((2, C), dtype=torch.float32, device=dev)
+    if dgamma is None:
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        accumulate = False
+    call("unetk_bn_act_bwd", ptr(g), ptr(y), ptr(dy), B, H, W, C, ptr(scale), ptr(shift), ptr(mean),
+         ptr(invstd), ptr(keep), 1 if relu else 0, ptr(dgamma), ptr(dbeta), 1 if accumulate else 0,
+         ptr(partials), ptr(sums), dtype_code(y.dtype), stream())
+    return dy, dgamma, dbeta
+
+
+def pool_bwd(a, dpooled, dskip=None):
+    B, H, W, C = a.shape
+    da = torch.empty_like(a)
+    # dskip may be a channel slice of a wider buffer: its pixel stride is what the kernel needs
+    call("unetk_pool_bwd", ptr(a), ptr(dpooled), ptr(dskip), dskip.stride(2) if dskip is not None else 0,
+         ptr(da), B, H, W, C, dtype_code(a.dtype), stream())
+    return da
+
+
+def upsample_concat(low, skip):
+    """cat(bilinear_resize(low -> skip's H,W), skip) along channels."""
+    B, h, w, C1 = low.shape
+    _, H, W, C2 = skip.shape
+    out = torch.empty((B, H, W, C1 + C2), dtype=low.dtype, device=low.device)
+    call("unetk_upsample_concat_fwd", ptr(low), h, w, C1, ptr(skip), C2, C2, ptr(out), B, H, W,
+         dtype_code(low.dtype), stream())
+    return out
+
+
+def upsample_bwd(dcat, C1, h, w):
+    """Gradient of the resized half of a concat buffer (B,H,W,C1+C2) -> (B,h,w,C1)."""
+    B, H, W, ld = dcat.shape
+    dlow = torch.empty((B, h, w, C1), dtype=dcat.dtype, device=dcat.device)
+    call("unetk_upsample_bwd", ptr(dcat), ld, H, W, ptr(dlow), B, h, w, C1, dtype_code(dcat.dtype), stream())
+    return dlow
+
+
+def head1x1_fwd(x, w, bias):
+    """x (B,H,W,C) NHWC, w (Co,C,1,1) fp32 -> (B,Co,H,W) fp32 NCHW."""
+    B, H, W, C = x.shape
+    Co = w.shape[0]
+    out = torch.empty((B, Co, H, W), dtype=torch.float32, device=x.device)
+    call("unetk_head1x1_fwd", ptr(x), C, ptr(w), ptr(bias), ptr(out), B, H, W, C, Co, dtype_code(x.dtype),
+         stream())
+    return out
+
+
+def head1x1_bwd(x, w, dout, need_dx=True):
+    """Returns (dx NHWC or None, dw (Co,C,1,1), db (Co,))."""
+    B, H, W, C = x.shape
+    Co = w.shape[0]
+    dev = x.device
+    dout = dout.contiguous().float()
+    dx = torch.empty_like(x) if need_dx else None
+    if Co != 1 and B != 1:
+        # general case: one reduction per output channel over a channel-major copy of dout
+        dw = torch.empty((Co, C), dtype=torch.float32, device=dev)
+        db = torch.empty(Co, dtype=torch.float32, device=dev)
+        nparts = _lib.load().unetk_reduce_num_partials(B * H * W)
+        partials = torch.empty((nparts, 2, C), dtype=torch.float32, device=dev)
+        if need_dx:
+            call("unetk_head1x1_bwd", ptr(x), C, ptr(w), ptr(dout), ptr(dx), None, None, B, H, W, C, Co, 0,
+                 ptr(partials), dtype_code(x.dtype), stream())
+        for o in range(Co):
+            d_o = dout[:, o].contiguous()
+            call("unetk_head1x1_bwd", ptr(x), C, ptr(w), ptr(d_o), None, ptr(dw[o]), ptr(db[o:o + 1]), B, H,
+                 W, C, 1, 0, ptr(partials), dtype_code(x.dtype), stream())
+        return dx, dw.view(Co, C, 1, 1), db
+    dw = torch.empty((Co, C), dtype=torch.float32, device=dev)
+    db = torch.empty(Co, dtype=torch.float32, device=dev)
+    nparts = _lib.load().unetk_reduce_num_partials(B * H * W)
+    partials = torch.empty((nparts, 2, C), dtype=torch.float32, device=dev)
+    call("unetk_head1x1_bwd", ptr(x), C, ptr(w), ptr(dout), ptr(dx), ptr(dw), ptr(db), B, H, W, C, Co, 0,
+         ptr(partials), dtype_code(x.dtype), stream())
+    return dx, dw.view(Co, C, 1, 1), db

@@ -1,0 +1,239 @@
+"""OptimizedUNet on hand-written gfx950 kernels.
+
+Drop-in for the reference class (training.py:455-531 == enhanced_training_multi_loss.py:516-602):
+same constructor, same ``state_dict`` keys and shapes (110 entries), same initialisation, same
+``forward(x: f32[B,C,H,W]) -> f32[B,out,H,W]`` and autograd behaviour.  Underneath, the whole
+network runs as one ``torch.autograd.Function``: activations are NHWC in the compute dtype
+(float32, or bfloat16 with fp32 accumulation), convolutions are MFMA implicit GEMMs with the
+BatchNorm statistics taken in their epilogue, and BatchNorm+ReLU+Dropout2d+MaxPool are one pass.
+"""
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+BLOCKS = ("encoder1", "encoder2", "encoder3", "encoder4", "bottleneck",
+          "decoder4", "decoder3", "decoder2", "decoder1")
+_DROPOUT_P = 0.05
+
+
+class OptimizedUNet(nn.Module):
+    """UNet regressor; ``compute_dtype`` (float32 or bfloat16) selects the kernel precision."""
+
+    def __init__(self, in_channels=4, out_channels=1, init_features=48, compute_dtype=torch.float32):
+        super().__init__()
+        f = init_features
+        self.in_channels, self.out_channels, self.init_features = in_channels, out_channels, f
+        self.compute_dtype = compute_dtype
+        self.encoder1 = self._block(in_channels, f)
+        self.pool1 = nn.MaxPool2d(kernel_size=2, stride=2)
+        self.encoder2 = self._block(f, f * 2)
+        self.pool2 = nn.MaxPool2d(kernel_size=2, stride=2)
+        self.encoder3 = self._block(f * 2, f * 4)
+        self.pool3 = nn.MaxPool2d(kernel_size=2, stride=2)
+        self.encoder4 = self._block(f * 4, f * 8)
+        self.pool4 = nn.MaxPool2d(kernel_size=2, stride=2)
+        self.bottleneck = self._block(f * 8, f * 16)
+        self.decoder4 = self._block(f * 8 + f * 16, f * 8)
+        self.decoder3 = self._block(f * 4 + f * 8, f * 4)
+        self.decoder2 = self._block(f * 2 + f * 4, f * 2)
+        self.decoder1 = self._block(f + f * 2, f)
+        self.conv = nn.Conv2d(f, out_channels, kernel_size=1)
+        self._initialize_weights()
+        # test hook: a list of nine (B, C) keep masks (0 or 1/(1-p)) used instead of fresh draws
+        self.dropout_masks_override: Optional[List[torch.Tensor]] = None
+
+    @staticmethod
+    def _block(cin, cout):
+        # parameter containers only: their own forward is never called
+        return nn.Sequential(
+            nn.Conv2d(cin, cout, kernel_size=3, padding=1, bias=False), nn.BatchNorm2d(cout),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(cout, cout, kernel_size=3, padding=1, bias=False), nn.BatchNorm2d(cout),
+            nn.ReLU(inplace=True), nn.Dropout2d(_DROPOUT_P))
+
+    def _initialize_weights(self):
+        # reference training.py:486-494
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("unet_amd.OptimizedUNet runs on the GPU only (hand-written gfx950 "
+                               "kernels, no CPU fallback); move the module and its input to 'cuda'")
+        if x.dim() != 4 or x.shape[1] != self.in_channels:
+            raise RuntimeError(f"expected input (B,{self.in_channels},H,W), got {tuple(x.shape)}")
+        params = list(self.parameters())
+        if self.training:
+            masks = self._draw_masks(x.shape[0], x.device)
+            return _UNetTrainFn.apply(x, self, masks, *params)
+        with torch.no_grad():
+            return _eval_forward(self, x)
+
+    def _draw_masks(self, B, device):
+        if self.dropout_masks_override is not None:
+            return [None if m is None else m.to(device=device, dtype=torch.float32).contiguous()
+                    for m in self.dropout_masks_override]
+        masks = []
+        for name in BLOCKS:
+            drop = getattr(self, name)[6]
+            p = drop.p
+            c = getattr(self, name)[3].out_channels
+            if p == 0.0:
+                masks.append(None)
+            else:
+                keep = torch.empty((B, c), dtype=torch.float32, device=device).bernoulli_(1 - p)
+                masks.append(keep.div_(1 - p))
+        return masks
+
+
+def _pack_all(model, dt, transpose):
+    packed = {}
+    for name in BLOCKS:
+        seq = getattr(model, name)
+        for ci in (0, 3):
+            packed[(name, ci)] = ops.PackedConv(seq[ci].weight, dt, transpose=transpose)
+    return packed
+
+
+def _eval_forward(model, x):
+    """Inference path: BatchNorm folded into the convolution epilogue, no Dropout."""
+    dt = model.compute_dtype
+    pk = _pack_all(model, dt, False)
+    h = ops.nchw_to_nhwc(x, dt)
+
+    def block(name, t):
+        seq = getattr(model, name)
+        for ci, bi in ((0, 1), (3, 4)):
+            bn = seq[bi]
+            sc, sh = ops.bn_fold_eval(bn.weight, bn.bias, bn.running_mean, bn.running_var, None, bn.eps)
+            t, _ = ops.conv_fwd(t, pk[(name, ci)], scale=sc, shift=sh, act=1)
+        return t
+
+    e1 = block("encoder1", h)
+    e2 = block("encoder2", ops.maxpool2x2(e1))
+    e3 = block("encoder3", ops.maxpool2x2(e2))
+    e4 = block("encoder4", ops.maxpool2x2(e3))
+    d = block("bottleneck", ops.maxpool2x2(e4))
+    for name, skip in (("decoder4", e4), ("decoder3", e3), ("decoder2", e2), ("decoder1", e1)):
+        d = block(name, ops.upsample_concat(d, skip))
+    return ops.head1x1_fwd(d, model.conv.weight, model.conv.bias)
+
+
+class _UNetTrainFn(torch.autograd.Function):
+    """Whole-network training forward/backward (BatchNorm uses batch statistics)."""
+
+    @staticmethod
+    def forward(ctx, x, model, masks, *params):
+        dt = model.compute_dtype
+        pk = _pack_all(model, dt, False)
+        saved = {}
+        B = x.shape[0]
+        h = ops.nchw_to_nhwc(x.detach(), dt)
+        saved["x"] = h
+
+        def block(name, t, keep, pool):
+            seq = getattr(model, name)
+            units = []
+            pooled = None
+            for u, (ci, bi) in enumerate(((0, 1), (3, 4))):
+                bn = seq[bi]
+                y, stats = ops.conv_fwd(t, pk[(name, ci)], want_stats=True)
+                Bn, H, W, _ = y.shape
+                mean, invstd, sc, sh = ops.bn_finalize(
+                    stats, Bn * H * W, bn.weight, bn.bias,
+                    bn.running_mean if bn.track_running_stats else None,
+                    bn.running_var if bn.track_running_stats else None, bn.eps,
+                    bn.momentum if bn.momentum is not None else 0.1)
+                if bn.track_running_stats:
+                    bn.num_batches_tracked += 1
+                last = u == 1
+                a, p = ops.bn_act_fwd(y, sc, sh, keep if last else None, relu=True, pool=pool and last)
+                units.append((t, y, mean, invstd, sc, sh))
+                t = a
+                if last:
+                    pooled = p
+            saved[name] = (units, t, keep)
+            return t, pooled
+
+        e1, p1 = block("encoder1", h, masks[0], True)
+        e2, p2 = block("encoder2", p1, masks[1], True)
+        e3, p3 = block("encoder3", p2, masks[2], True)
+        e4, p4 = block("encoder4", p3, masks[3], True)
+        d, _ = block("bottleneck", p4, masks[4], False)
+        for i, (name, skip) in enumerate((("decoder4", e4), ("decoder3", e3), ("decoder2", e2),
+                                          ("decoder1", e1))):
+            low_hw = d.shape[1:3]
+            cat = ops.upsample_concat(d, skip)
+            saved[name + ".low"] = (low_hw, d.shape[3])
+            d, _ = block(name, cat, masks[5 + i], False)
+        out = ops.head1x1_fwd(d, model.conv.weight, model.conv.bias)
+        ctx.model = model
+        ctx.saved = saved
+        ctx.need_dx = ctx.needs_input_grad[0]
+        ctx.in_shape = x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        model, saved = ctx.model, ctx.saved
+        dt = model.compute_dtype
+        pkT = _pack_all(model, dt, True)
+        grads = {}
+
+        # final 1x1 conv
+        units_d1, a_d1, _ = saved["decoder1"]
+        g, dw, db = ops.head1x1_bwd(a_d1, model.conv.weight, dout)
+        grads["conv.weight"], grads["conv.bias"] = dw, db
+
+        def block_bwd(name, g, need_dx=True):
+            seq = getattr(model, name)
+            units, a_out, keep = saved[name]
+            for u in (1, 0):
+                ci, bi = ((0, 1), (3, 4))[u]
+                t_in, y, mean, invstd, sc, sh = units[u]
+                dy, dgamma, dbeta = ops.bn_act_bwd(g, y, sc, sh, mean, invstd,
+                                                   keep if u == 1 else None, relu=True)
+                grads[f"{name}.{bi}.weight"], grads[f"{name}.{bi}.bias"] = dgamma, dbeta
+                conv = seq[ci]
+                grads[f"{name}.{ci}.weight"] = ops.conv_wgrad(t_in, dy, conv.in_channels,
+                                                              conv.out_channels, 3)
+                if u == 1 or need_dx:
+                    g, _ = ops.conv_fwd(dy, pkT[(name, ci)])
+                else:
+                    g = None
+            return g
+
+        g = block_bwd("decoder1", g)
+        enc_names = ("encoder1", "encoder2", "encoder3", "encoder4")
+        dskips = {}
+        for name, enc in (("decoder1", "encoder1"), ("decoder2", "encoder2"), ("decoder3", "encoder3"),
+                          ("decoder4", "encoder4")):
+            if name != "decoder1":
+                g = block_bwd(name, g)
+            (lh, lw), C1 = saved[name + ".low"]
+            dskips[enc] = (g, C1)          # skip gradient = channels [C1:] of the concat gradient
+            g = ops.upsample_bwd(g, C1, lh, lw)
+        g = block_bwd("bottleneck", g)
+        for enc in reversed(enc_names):
+            _, a_enc, _ = saved[enc]
+            dcat, C1 = dskips[enc]
+            g = ops.pool_bwd(a_enc, g, dcat[..., C1:])
+            g = block_bwd(enc, g, need_dx=(enc != "encoder1") or ctx.need_dx)
+        dx = None
+        if ctx.need_dx:
+            dx = ops.nhwc_to_nchw(g, ctx.in_shape[1])
+        ctx.saved = None
+        out_grads = []
+        for n, p in model.named_parameters():
+            out_grads.append(grads[n] if p.requires_grad else None)
+        return (dx, None, None, *out_grads)
