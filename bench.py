@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""Headline benchmark: UNet training step (forward + multi-loss + backward) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the hot path over one synthetic batch that is already resident in HBM:
+OptimizedUNet(4,1,48) forward, the 'all' multi-loss, backward to every parameter (and, for N > 1,
+the data-parallel gradient all-reduce over RCCL).  Workload = BASELINE config 2: batch 64 of
+4x256x256 patches per GPU, bf16 storage with fp32 accumulation.  Rank 0 prints ONE JSON line.
+
+The line also carries
+  roofline     - the MFMA implicit-GEMM conv family (forward + data-gradient launches): algorithmic
+                 FLOPs of those launches / their summed duration, measured with events on the
+                 launch stream in an extra instrumented step, against the 2.5 PFLOP/s dense bf16 peak;
+  cpu_baseline - the CPU oracle (torch fp32) timed on this host on a bounded sample of the same
+                 workload (batch 4, same network and loss).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak of MI355X
+PEAK_F32_TFLOPS = 157.3
+LOSS_CFG = {   # training_variants.py:119-130 "all" preset
+    "loss_combination": "all", "pixel_loss_weight": 1.0, "gradient_loss_weight": 0.3,
+    "spectral_loss_weight": 0.2, "pixel_loss_type": "mse", "use_tid_weights": True,
+    "tid_weight_scale": 1.0, "gradient_method": "sobel", "spectral_focus_high_freq": True,
+    "high_freq_weight_factor": 2.0,
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def make_loss():
+    try:
+        from unet_amd.losses import MultiLossFunction
+        return MultiLossFunction(LOSS_CFG), "all"
+    except ImportError:
+        return None, "mse"
+
+
+def train_step(model, crit, x, y, w):
+    for p in model.parameters():
+        p.grad = None
+    out = model(x)
+    if crit is not None:
+        loss, _ = crit(out, y, w)
+    else:
+        loss = ((out - y) ** 2).mean()
+    loss.backward()
+    return loss
+
+
+def conv_family_roofline(model, crit, x, y, w, dt):
+    """Instrument every implicit-GEMM conv launch of one step with events on the launch stream."""
+    from unet_amd import ops
+    records = []
+    orig = ops.conv_fwd
+
+    def timed(xin, pw, *a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig(xin, pw, *a, **k)
+        e1.record()
+        B, H, W_, _ = xin.shape
+        flops = 2.0 * B * H * W_ * pw.Co * pw.Ci * pw.ks * pw.ks
+        records.append((e0, e1, flops))
+        return r
+
+    ops.conv_fwd = timed
+    try:
+        train_step(model, crit, x, y, w)
+        torch.cuda.synchronize()
+    finally:
+        ops.conv_fwd = orig
+    ms = sum(e0.elapsed_time(e1) for e0, e1, _ in records)
+    flops = sum(f for _, _, f in records)
+    achieved = flops / (ms * 1e-3) / 1e12
+    peak = PEAK_BF16_TFLOPS if dt == torch.bfloat16 else PEAK_F32_TFLOPS
+    return {"bound": "mfma", "kernel": "conv_igemm_kernel (forward + data-gradient launches)",
+            "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+            "traffic": None, "launches": len(records), "ms_per_step_in_kernel": round(ms, 3),
+            "algorithmic_tflop_per_step": round(flops / 1e12, 3)}
+
+
+def cpu_baseline(batch, size):
+    """The CPU oracle on a bounded sample: UNet(4,1,48) fwd + 'all' loss + bwd, batch `batch`."""
+    from oracle import loss_oracle, unet_oracle
+    from oracle import weights as W
+    threads = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(threads)
+    sd = W.fill_state_dict(W.unet_template(4, 1, 48), seed=42)
+    x, y, w = W.synthetic_batch(batch, 4, size, size, seed=42)
+    cfg = loss_oracle.preset("all")
+    times = []
+    for i in range(3):
+        t0 = time.perf_counter()
+        unet_oracle.unet_fwd_bwd(sd, x, lambda o: loss_oracle.multi_loss(cfg, o, y, w)[0])
+        times.append(time.perf_counter() - t0)
+    t = min(times[1:])
+    return {"value": round(batch / t, 3), "unit": "patches/s", "cores": threads, "kind": "port",
+            "sample": f"torch-CPU fp32 oracle, batch {batch} of 4x{size}x{size}, fwd+loss+bwd, best of 2 after 1 warm-up"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    from oracle import weights as W
+    from unet_amd import OptimizedUNet
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model = OptimizedUNet(4, 1, 48, compute_dtype=dt)
+    model.load_state_dict(W.fill_state_dict(W.unet_template(4, 1, 48), seed=42))
+    model = model.to(dev).train()
+    crit, loss_name = make_loss()
+    if crit is not None:
+        crit = crit.to(dev)
+    x, y, w = W.synthetic_batch(args.batch, 4, args.size, args.size, seed=42 + rank)
+    x, y, w = x.to(dev), y.to(dev), w.to(dev)
+
+    reducer = None
+    if world > 1:
+        from unet_amd.dist import GradReducer
+        reducer = GradReducer(model)
+
+    def step():
+        loss = train_step(model, crit, x, y, w)
+        if reducer is not None:
+            reducer.allreduce()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = t.item()
+    ms = el / args.steps * 1e3
+    value = world * args.batch * args.steps / el
+
+    roof = None
+    cpu = None
+    if rank == 0:
+        if not args.no_roofline:
+            roof = conv_family_roofline(model, crit, x, y, w, dt)
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline(4, args.size)
+        line = {
+            "metric": "train patches/s (fwd+bwd)", "value": round(value, 2), "unit": "patches/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"UNet(4,1,48) training step fwd+loss({loss_name})+bwd, batch {args.batch}/GPU of "
+                                   f"4x{args.size}x{args.size}, {args.dtype} storage fp32 accumulate",
+                       "global_batch": world * args.batch, "patch": args.size,
+                       "parallelism": f"dp{world}" if world > 1 else "single"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -81,7 +81,8 @@ int unetk_bn_fold_eval(const float* gamma, const float* beta, const float* runni
 int unetk_bn_act_fwd(const void* y, void* a, void* pooled, int B, int H, int W, int C, const float* scale,
                      const float* shift, const float* keep, int relu, int dtype, unetk_stream_t stream);
 int unetk_reduce_num_partials(int64_t npix);
-/* dy = BN'(relu'(keep * g)); dgamma/dbeta (nullable) (+)=.  partials: [num_partials][2][C], sums: [2][C] */
+/* dy = BN'(relu'(keep * g)); dgamma/dbeta (nullable) (+)=.
+ * scratch owned by the caller: partials [num_partials][2][C] floats, sums [6][C] floats */
 int unetk_bn_act_bwd(const void* g, const void* y, void* dy, int B, int H, int W, int C,
                      const float* scale, const float* shift, const float* mean, const float* invstd,
                      const float* keep, int relu, float* dgamma, float* dbeta, int accumulate,

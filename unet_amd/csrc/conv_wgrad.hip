@@ -173,21 +173,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       }
 }
 
-// dw[co][ci][tap] (+)= sum_s slab[s][co][tap][ci]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nslab,
-                                    int Co, int Ci, int Co_pad, int Ci_pad, int taps, int accumulate) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long total = (long)Co * taps * Ci;
-  if (idx >= total) return;
-  const int ci = idx % Ci;
-  const int tap = (idx / Ci) % taps;
-  const int co = idx / ((long)Ci * taps);
+// dw[co][ci][tap] (+)= sum_s slab[s][co][tap][ci].  One workgroup per (co, tap, 32-channel chunk):
+// 32 channel lanes x 8 slab lanes, slabs summed in a fixed order (bitwise reproducible).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab,
+                                                           float* __restrict__ dw, int nslab, int Co, int Ci,
+                                                           int Co_pad, int Ci_pad, int taps,
+                                                           int accumulate) {
+  __shared__ float red[8][32];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int nchunk = Ci_pad / 32;
+  int t = blockIdx.x;
+  const int chunk = t % nchunk;
+  t /= nchunk;
+  const int tap = t % taps;
+  const int co = t / taps;
+  const int ci = chunk * 32 + cl;
   const long stride = (long)Co_pad * taps * Ci_pad;
   const float* p = slab + ((long)co * taps + tap) * Ci_pad + ci;
   float s = 0.f;
-  for (int i = 0; i < nslab; ++i) s += p[i * stride];
-  float* d = dw + ((long)co * Ci + ci) * taps + tap;
-  *d = accumulate ? (*d + s) : s;
+  for (int i = sl; i < nslab; i += 8) s += p[i * stride];
+  red[sl][cl] = s;
+  __syncthreads();
+  if (sl == 0 && ci < Ci) {
+    float tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tot += red[k][cl];
+    float* d = dw + ((long)co * Ci + ci) * taps + tap;
+    *d = accumulate ? (*d + tot) : tot;
+  }
 }
 
 struct WgradPlan {
@@ -207,6 +220,7 @@ WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int dtype) {
   p.Ci_pad = cdiv(Ci, 32) * 32;
   const int gxy = (p.Ci_pad / 32) * (p.Co_pad / (p.mt * 16));
   int s = 1536 / gxy;
+  if (s > 256) s = 256;
   if (s < 1) s = 1;
   if (s > p.ntiles) s = p.ntiles;
   p.nsplit = s;
@@ -261,8 +275,8 @@ int unetk_conv_wgrad(const void* in, int ldin, const void* dy, int lddy, float* 
   else
     rc = ks == 3 ? launch_wgrad<float, 3>(a, p, stream) : launch_wgrad<float, 1>(a, p, stream);
   if (rc != UNETK_OK) return rc;
-  const long total = (long)Co * ks * ks * Ci;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, a.slab, dw,
+  const long nblocks = (long)Co * ks * ks * (p.Ci_pad / 32);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)nblocks), dim3(256), 0, stream, a.slab, dw,
                      2 * p.nsplit, Co, Ci, p.Co_pad, p.Ci_pad, ks * ks, accumulate);
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;

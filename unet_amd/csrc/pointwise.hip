@@ -267,36 +267,76 @@ __global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restric
   }
 }
 
-// dy = scale * (dz - sum_dz/n - xhat * sum_dzxhat/n)
+// Per-channel coefficients of the BatchNorm backward: with dz = keep * g * [z > 0],
+//   dy = scale * (dz - sum_dz/n - xhat * sum_dzxhat/n) = scale*dz + k1*y + k0,
+//   k1 = -scale * sum_dzxhat * invstd / n,   k0 = -scale * sum_dz / n - k1 * mean.
+// coef: [4][C] = scale, shift, k1, k0
+__global__ void bn_bwd_coef_kernel(const float* __restrict__ scale, const float* __restrict__ shift,
+                                   const float* __restrict__ mean, const float* __restrict__ invstd,
+                                   const float* __restrict__ sums, float inv_n, float* __restrict__ coef,
+                                   int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = scale[c];
+  const float k1 = -sc * sums[C + c] * invstd[c] * inv_n;
+  coef[c] = sc;
+  coef[C + c] = shift[c];
+  coef[2 * C + c] = k1;
+  coef[3 * C + c] = -sc * sums[c] * inv_n - k1 * mean[c];
+}
+
+template <int E> __device__ __forceinline__ void load_params(const float* p, float (&out)[E]) {
+#pragma unroll
+  for (int i = 0; i < E; i += 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p + i);
+    out[i] = v[0];
+    out[i + 1] = v[1];
+    out[i + 2] = v[2];
+    out[i + 3] = v[3];
+  }
+}
+
+// Threads are (pixel lane, channel group); each keeps its channel group's coefficients in
+// registers and streams over the pixels of the workgroup's chunk.
 template <typename T>
-__global__ void bn_act_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ y, T* __restrict__ dy,
-                                        long npix, long hw, int C, const float* __restrict__ scale,
-                                        const float* __restrict__ shift, const float* __restrict__ mean,
-                                        const float* __restrict__ invstd, const float* __restrict__ keep,
-                                        const float* __restrict__ sum_dz, const float* __restrict__ sum_dzx,
-                                        float inv_n, int relu) {
+__global__ __launch_bounds__(RED_THREADS) void bn_act_bwd_apply_kernel(
+    const T* __restrict__ g, const T* __restrict__ y, T* __restrict__ dy, unsigned npix, unsigned hw, int C,
+    const float* __restrict__ coef, const float* __restrict__ keep, int relu, unsigned chunk) {
   constexpr int E = Vec16<T>::N;
   const int CG = C / E;
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= npix * CG) return;
-  const int cg = idx % CG;
-  const long p = idx / CG;
+  const int lanes = RED_THREADS / CG;
+  const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
+  if (pl >= lanes) return;
   const int c0 = cg * E;
-  const int b = p / hw;
-  Vec16<T> gv = load16(g + p * C + c0);
-  Vec16<T> yv = load16(y + p * C + c0);
-  Vec16<T> o;
+  float sc[E], sh[E], k1[E], k0[E];
+  load_params<E>(coef + c0, sc);
+  load_params<E>(coef + C + c0, sh);
+  load_params<E>(coef + 2 * C + c0, k1);
+  load_params<E>(coef + 3 * C + c0, k0);
+  const unsigned pbeg = blockIdx.x * chunk;
+  unsigned pend = pbeg + chunk;
+  if (pend > npix) pend = npix;
+  for (unsigned p = pbeg + pl; p < pend; p += lanes) {
+    const size_t off = (size_t)p * C + c0;
+    Vec16<T> gv = load16(g + off);
+    Vec16<T> yv = load16(y + off);
+    float kp[E];
+    if (keep != nullptr) {
+      load_params<E>(keep + (size_t)(p / hw) * C + c0, kp);
+    } else {
 #pragma unroll
-  for (int e = 0; e < E; ++e) {
-    const int c = c0 + e;
-    const float yy = to_f32(yv.v[e]);
-    float dz = to_f32(gv.v[e]);
-    if (keep) dz *= keep[(long)b * C + c];
-    if (relu && !(yy * scale[c] + shift[c] > 0.f)) dz = 0.f;
-    const float xh = (yy - mean[c]) * invstd[c];
-    o.v[e] = from_f32<T>(scale[c] * (dz - sum_dz[c] * inv_n - xh * sum_dzx[c] * inv_n));
+      for (int e = 0; e < E; ++e) kp[e] = 1.f;
+    }
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const float yy = to_f32(yv.v[e]);
+      float dz = to_f32(gv.v[e]) * kp[e];
+      if (relu && !(yy * sc[e] + sh[e] > 0.f)) dz = 0.f;
+      o.v[e] = from_f32<T>(sc[e] * dz + k1[e] * yy + k0[e]);
+    }
+    store16(dy + off, o);
   }
-  store16(dy + p * C + c0, o);
 }
 
 // ------------------------------------------------------------------ 2x2 max-pool backward (+ skip grad)
@@ -610,6 +650,7 @@ int unetk_bn_act_bwd(const void* g, const void* y, void* dy, int B, int H, int W
   const int E = dtype == UNETK_BF16 ? 8 : 4;
   UNETK_CHECK_ARG(C / E <= RED_THREADS, "bn_act_bwd: too many channels (%d)", C);
   const long npix = (long)B * H * W;
+  UNETK_CHECK_ARG(npix < (1L << 31), "bn_act_bwd: too many pixels");
   const int nblk = reduce_blocks(npix);
   RedArgs r;
   r.x = y; r.g = g; r.scale = scale; r.shift = shift; r.mean = mean; r.invstd = invstd; r.keep = keep;
@@ -627,10 +668,21 @@ int unetk_bn_act_bwd(const void* g, const void* y, void* dy, int B, int H, int W
                        dgamma, accumulate);
     UNETK_CHECK_LAUNCH();
   }
-  const long total = npix * (C / E);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_bwd_apply_kernel<T>, dim3(cdiv(total, 256)), dim3(256), 0,
-                                       stream, (const T*)g, (const T*)y, (T*)dy, npix, (long)H * W, C, scale,
-                                       shift, mean, invstd, keep, sums, sums + C, 1.0f / (float)npix, relu));
+  // coefficients live behind the two sum rows: sums must hold 6*C floats
+  float* coef = sums + 2 * C;
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, scale, shift, mean, invstd,
+                     sums, 1.0f / (float)npix, coef, C);
+  UNETK_CHECK_LAUNCH();
+  {
+    const int lanes = RED_THREADS / (C / E);
+    long nb = (npix + (long)lanes * 8 - 1) / ((long)lanes * 8);
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    const unsigned chunk = (unsigned)((npix + nb - 1) / nb);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_bwd_apply_kernel<T>, dim3((unsigned)cdiv(npix, chunk)),
+                                         dim3(RED_THREADS), 0, stream, (const T*)g, (const T*)y, (T*)dy,
+                                         (unsigned)npix, (unsigned)((long)H * W), C, coef, keep, relu, chunk));
+  }
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }

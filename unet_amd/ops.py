@@ -163,7 +163,7 @@ def bn_act_bwd(g, y, scale, shift, mean, invstd, keep=None, relu=True, dgamma=No
     dy = torch.empty_like(y)
     nparts = _lib.load().unetk_reduce_num_partials(B * H * W)
     partials = torch.empty((nparts, 2, C), dtype=torch.float32, device=dev)
-    sums = torch.empty((2, C), dtype=torch.float32, device=dev)
+    sums = torch.empty((6, C), dtype=torch.float32, device=dev)
     if dgamma is None:
         dgamma = torch.empty(C, dtype=torch.float32, device=dev)
         dbeta = torch.empty(C, dtype=torch.float32, device=dev)
