@@ -106,6 +106,33 @@ int unetk_head1x1_bwd(const void* x, int ldx, const float* w, const float* dout,
                       float* db, int B, int H, int W, int C, int Co, int accumulate, float* partials,
                       int dtype, unetk_stream_t stream);
 
+/* ---- multi-loss reductions ----------------------------------------------------------
+ * TIDWeightedLoss / GradientLoss / SpectralLoss / MultiLossFunction,
+ * enhanced_training_multi_loss.py:143-416 (== training.py:158-365).  pred/target/w are fp32
+ * (B,1,H,W); w may be null.  `res` is a 16-float device record: [0] pixel [1] gradient
+ * [2] spectral [3] total, [4..11] normalisation coefficients consumed by the backward kernels.
+ * pixel_mae: 0 mse / 1 mae; grad_method: 0 none / 1 sobel / 2 diff. */
+int unetk_loss_num_partials(int B, int H, int W);
+int unetk_loss_spectral_blocks(int H, int W);
+/* partials: [num_partials][11] floats; gx, gy: (B,H,W) Sobel maps of pred-target (sobel only) */
+int unetk_loss_pixgrad_fwd(const float* pred, const float* target, const float* w, int B, int H, int W,
+                           int pixel_mae, int grad_method, int pixel_use_w, float tid_scale, float* gx,
+                           float* gy, float* partials, float* res, unetk_stream_t stream);
+/* Fp, Ft: complex64 fft2 of pred / target (B,H,W); partials, wsum: [B][spectral_blocks]; coef: [B] */
+int unetk_loss_spectral_fwd(const void* Fp, const void* Ft, const float* w, int B, int H, int W, float factor,
+                            float* partials, float* wsum, float* coef, float* res, unetk_stream_t stream);
+int unetk_loss_combine(float* res, float w_pixel, float w_grad, float w_spec, int use_grad, int use_spec,
+                       unetk_stream_t stream);
+/* dpred (+)= gout[0] * (w_pixel * d pixel/d pred + w_grad * d gradient/d pred) */
+int unetk_loss_pixgrad_bwd(const float* pred, const float* target, const float* w, int B, int H, int W,
+                           int pixel_mae, int grad_method, const float* gx, const float* gy, const float* res,
+                           const float* gout, float w_pixel, float w_grad, int use_grad, float* dpred,
+                           int accumulate, unetk_stream_t stream);
+/* Z (complex64, B,H,W): d spectral/d pred = Re(fft2(Z)) */
+int unetk_loss_spectral_bwd(const void* Fp, const void* Ft, int B, int H, int W, float factor,
+                            const float* coef, float w_spec, const float* gout, void* Z,
+                            unetk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

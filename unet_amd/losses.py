@@ -1,0 +1,185 @@
+"""Multi-loss functions on gfx950 reduction kernels.
+
+Drop-in for the reference classes (enhanced_training_multi_loss.py:143-416 == training.py:158-365):
+``TIDWeightedLoss``, ``GradientLoss``, ``SpectralLoss`` and ``MultiLossFunction(config)`` with
+``forward(pred, target, tid_weights=None) -> (total, {'pixel','gradient','spectral','total'})``.
+The pixel and gradient terms are one fused pass; the spectral term uses the FFT library through
+``torch.fft`` for the two transforms and a fused kernel for everything after them.  The loss parts
+stay on the device until the dict of floats is built, which costs one device-to-host copy.
+"""
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import call, ptr, stream
+
+_METHODS = {"none": 0, "sobel": 1, "diff": 2}
+
+
+def _check(pred, target, w):
+    if not pred.is_cuda:
+        raise RuntimeError("unet_amd losses run on the GPU only (no CPU fallback)")
+    if pred.dim() != 4 or pred.shape[1] != 1 or pred.shape != target.shape:
+        raise RuntimeError(f"expected pred/target of shape (B,1,H,W), got {tuple(pred.shape)} / {tuple(target.shape)}")
+    if w is not None and w.shape != pred.shape:
+        raise RuntimeError("tid_weights must have the shape of pred")
+
+
+class _MultiLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, w, cfg):
+        lib = _lib.load()
+        p = pred.detach().contiguous().float()
+        t = target.detach().contiguous().float()
+        wt = None if w is None else w.detach().contiguous().float()
+        B, _, H, W = p.shape
+        dev = p.device
+        res = torch.zeros(16, dtype=torch.float32, device=dev)
+        method = cfg["grad_method"] if cfg["use_grad"] else 0
+        gx = gy = None
+        if method == 1:
+            gx = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+            gy = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+        partials = torch.empty((lib.unetk_loss_num_partials(B, H, W), 11), dtype=torch.float32, device=dev)
+        w_pix = wt if cfg["pixel_w"] else None
+        call("unetk_loss_pixgrad_fwd", ptr(p), ptr(t), ptr(wt), B, H, W, cfg["mae"], method,
+             1 if (cfg["pixel_w"] and wt is not None) else 0, cfg["tid_scale"], ptr(gx), ptr(gy),
+             ptr(partials), ptr(res), stream())
+        Fp = Ft = coef = None
+        if cfg["use_spec"]:
+            Fp = torch.fft.fft2(p[:, 0])
+            Ft = torch.fft.fft2(t[:, 0])
+            nb = lib.unetk_loss_spectral_blocks(H, W)
+            sp = torch.empty((B, nb), dtype=torch.float32, device=dev)
+            ws = torch.empty((B, nb), dtype=torch.float32, device=dev)
+            coef = torch.empty(B, dtype=torch.float32, device=dev)
+            call("unetk_loss_spectral_fwd", ptr(Fp), ptr(Ft), ptr(wt), B, H, W, cfg["hf_factor"], ptr(sp),
+                 ptr(ws), ptr(coef), ptr(res), stream())
+        call("unetk_loss_combine", ptr(res), cfg["w_pixel"], cfg["w_grad"], cfg["w_spec"],
+             1 if cfg["use_grad"] else 0, 1 if cfg["use_spec"] else 0, stream())
+        ctx.cfg, ctx.method = cfg, method
+        ctx.tensors = (p, t, wt, gx, gy, res, Fp, Ft, coef)
+        ctx.mark_non_differentiable(res)
+        return res[3].clone(), res
+
+    @staticmethod
+    def backward(ctx, gout, _gres):
+        cfg, method = ctx.cfg, ctx.method
+        p, t, wt, gx, gy, res, Fp, Ft, coef = ctx.tensors
+        B, _, H, W = p.shape
+        go = gout.detach().reshape(1).contiguous().float()
+        dpred = torch.empty_like(p)
+        call("unetk_loss_pixgrad_bwd", ptr(p), ptr(t), ptr(wt), B, H, W, cfg["mae"], method, ptr(gx), ptr(gy),
+             ptr(res), ptr(go), cfg["w_pixel"], cfg["w_grad"], 1 if cfg["use_grad"] else 0, ptr(dpred), 0,
+             stream())
+        if cfg["use_spec"]:
+            Z = torch.empty_like(Fp)
+            call("unetk_loss_spectral_bwd", ptr(Fp), ptr(Ft), B, H, W, cfg["hf_factor"], ptr(coef),
+                 cfg["w_spec"], ptr(go), ptr(Z), stream())
+            dpred += torch.fft.fft2(Z).real.unsqueeze(1)
+        return dpred, None, None, None
+
+
+def _run(pred, target, w, cfg):
+    _check(pred, target, w)
+    return _MultiLossFn.apply(pred, target, w, cfg)
+
+
+def _cfg(mae=0, pixel_w=True, tid_scale=1.0, grad_method=1, hf_factor=2.0, w_pixel=1.0, w_grad=0.0,
+         w_spec=0.0, use_grad=False, use_spec=False):
+    return dict(mae=mae, pixel_w=pixel_w, tid_scale=float(tid_scale), grad_method=grad_method,
+                hf_factor=float(hf_factor), w_pixel=float(w_pixel), w_grad=float(w_grad), w_spec=float(w_spec),
+                use_grad=use_grad, use_spec=use_spec)
+
+
+class TIDWeightedLoss(nn.Module):
+    """reference enhanced_training_multi_loss.py:143-184"""
+
+    def __init__(self, loss_type="mse", use_tid_weights=True, tid_weight_scale=1.0):
+        super().__init__()
+        if loss_type not in ("mse", "mae"):
+            raise ValueError(f"unsupported loss type: {loss_type}")
+        self.loss_type, self.use_tid_weights, self.tid_weight_scale = loss_type, use_tid_weights, tid_weight_scale
+
+    def forward(self, pred, target, tid_weights=None):
+        w = tid_weights if self.use_tid_weights else None
+        total, _ = _run(pred, target, w, _cfg(mae=int(self.loss_type == "mae"), pixel_w=True,
+                                               tid_scale=self.tid_weight_scale))
+        return total
+
+
+class GradientLoss(nn.Module):
+    """reference enhanced_training_multi_loss.py:187-269"""
+
+    def __init__(self, method="sobel"):
+        super().__init__()
+        self.method = method
+        if method == "sobel":
+            sx = torch.tensor([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]], dtype=torch.float32)
+            sy = torch.tensor([[-1, -2, -1], [0, 0, 0], [1, 2, 1]], dtype=torch.float32)
+            self.register_buffer("sobel_x", sx.view(1, 1, 3, 3))
+            self.register_buffer("sobel_y", sy.view(1, 1, 3, 3))
+
+    def forward(self, pred, target, tid_weights=None):
+        if self.method not in ("sobel", "diff"):
+            # the reference leaves the gradient tensors unbound for any other method
+            raise UnboundLocalError("local variable 'pred_grad_x' referenced before assignment")
+        total, _ = _run(pred, target, tid_weights,
+                        _cfg(pixel_w=False, grad_method=_METHODS[self.method], w_pixel=0.0, w_grad=1.0,
+                             use_grad=True))
+        return total
+
+
+class SpectralLoss(nn.Module):
+    """reference enhanced_training_multi_loss.py:272-344"""
+
+    def __init__(self, focus_high_freq=True, high_freq_weight_factor=2.0):
+        super().__init__()
+        self.focus_high_freq, self.high_freq_weight_factor = focus_high_freq, high_freq_weight_factor
+
+    def forward(self, pred, target, tid_weights=None):
+        if not self.focus_high_freq:
+            raise NameError("name 'H' is not defined")     # reference :338 reads H, W unbound
+        total, _ = _run(pred, target, tid_weights,
+                        _cfg(pixel_w=False, hf_factor=self.high_freq_weight_factor, w_pixel=0.0, w_spec=1.0,
+                             use_spec=True))
+        return total
+
+
+class MultiLossFunction(nn.Module):
+    """reference enhanced_training_multi_loss.py:347-416"""
+
+    def __init__(self, config: Dict):
+        super().__init__()
+        self.config = config
+        self.pixel_loss = TIDWeightedLoss(config["pixel_loss_type"], config["use_tid_weights"],
+                                          config["tid_weight_scale"])
+        self.gradient_loss = GradientLoss(method=config["gradient_method"])
+        self.spectral_loss = SpectralLoss(config["spectral_focus_high_freq"], config["high_freq_weight_factor"])
+        self.pixel_weight = config["pixel_loss_weight"]
+        self.gradient_weight = config["gradient_loss_weight"]
+        self.spectral_weight = config["spectral_loss_weight"]
+        self.loss_combination = config["loss_combination"]
+
+    def forward(self, pred, target, tid_weights: Optional[torch.Tensor] = None):
+        comb = self.loss_combination
+        use_grad = comb in ("weighted_mse_grad", "all") and self.gradient_weight > 0
+        use_spec = comb in ("weighted_mse_fft", "all") and self.spectral_weight > 0
+        if use_grad and self.gradient_loss.method not in ("sobel", "diff"):
+            raise UnboundLocalError("local variable 'pred_grad_x' referenced before assignment")
+        if use_spec and not self.spectral_loss.focus_high_freq:
+            raise NameError("name 'H' is not defined")
+        pixel_w = self.pixel_loss.use_tid_weights and comb != "baseline"
+        cfg = _cfg(mae=int(self.pixel_loss.loss_type == "mae"), pixel_w=pixel_w,
+                   tid_scale=self.pixel_loss.tid_weight_scale,
+                   grad_method=_METHODS.get(self.gradient_loss.method, 0),
+                   hf_factor=self.spectral_loss.high_freq_weight_factor, w_pixel=self.pixel_weight,
+                   w_grad=self.gradient_weight, w_spec=self.spectral_weight, use_grad=use_grad,
+                   use_spec=use_spec)
+        total, res = _run(pred, target, tid_weights, cfg)
+        vals = res[:4].tolist()          # the one device-to-host copy of the step
+        losses = {"pixel": vals[0], "gradient": vals[1] if use_grad else 0.0,
+                  "spectral": vals[2] if use_spec else 0.0, "total": vals[3]}
+        return total, losses
