@@ -133,6 +133,23 @@ int unetk_loss_spectral_bwd(const void* Fp, const void* Ft, int B, int H, int W,
                             const float* coef, float w_spec, const float* gout, void* Z,
                             unetk_stream_t stream);
 
+/* ---- tiled large-area inference -------------------------------------------------------
+ * LargeAreaPredictor.predict_large_area, large_area_predictor.py:151-216.
+ * feats: (nvar, lat, lon) fp32.  Tiles start at (ti*S, tj*S), ti < nti, tj < ntj, lat-major. */
+/* valid[ti*ntj+tj] = 0 when some variable is all-NaN in the window (:168-170) */
+int unetk_tile_valid(const float* feats, int nvar, int lat, int lon, int P, int S, int nti, int ntj,
+                     int* valid, unetk_stream_t stream);
+/* pos: n (lat_start, lon_start) pairs -> NHWC batch (n,P,P,ld), NaN -> 0 (:178-179) */
+int unetk_tile_gather(const float* feats, int nvar, int lat, int lon, const int* pos, int n, int P, void* out,
+                      int ld, int dtype, unetk_stream_t stream);
+/* Adds tiles [t0,t1) of the compacted tile list (pred: (t1-t0,P,P) fp32; slot[ti*ntj+tj] = index in
+ * that list or -1) into acc/cnt for rows [row0,row1), per pixel in tile order (:202-212). */
+int unetk_blend_accumulate(const float* pred, const float* wk, const int* slot, int t0, int t1, int nti,
+                           int ntj, int P, int S, float* acc, float* cnt, int lat, int lon, int row0, int row1,
+                           unetk_stream_t stream);
+/* out = acc / (cnt > 1e-9 ? cnt : 1)  (:215-216) */
+int unetk_blend_normalize(const float* acc, const float* cnt, float* out, int64_t n, unetk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

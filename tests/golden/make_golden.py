@@ -196,14 +196,23 @@ class _DS(dict):
 
 
 class _ToyNet(torch.nn.Module):
-    """Cheap deterministic stand-in model: a fixed 3x3 conv over the 4 channels."""
+    """Cheap deterministic stand-in model: a fixed 3x3 conv over the 4 channels, then x/(1+|x|)."""
     def __init__(self):
         super().__init__()
         g = np.random.Generator(np.random.PCG64(5))
         self.w = torch.from_numpy(g.normal(0, 0.3, (1, 4, 3, 3)).astype(np.float32))
 
     def forward(self, x):
-        return torch.tanh(torch.nn.functional.conv2d(x, self.w, padding=1))
+        # explicit shifted multiply-adds in a fixed order and IEEE-exact elementwise ops only, so
+        # the bits of a sample's output do not depend on batch size, threading or vector tails
+        xp = torch.nn.functional.pad(x, (1, 1, 1, 1))
+        H, Wd = x.shape[2], x.shape[3]
+        acc = torch.zeros((x.shape[0], H, Wd), dtype=x.dtype)
+        for c in range(4):
+            for ky in range(3):
+                for kx in range(3):
+                    acc = acc + xp[:, c, ky:ky + H, kx:kx + Wd] * self.w[0, c, ky, kx]
+        return (acc / (1.0 + acc.abs())).unsqueeze(1)
 
 
 def toy_features(lat, lon, seed, nan_block=None, nan_speckle=0.0):

@@ -57,6 +57,10 @@ _SIGNATURES = {
     "unetk_loss_combine": (I, [P, F, F, F, I, I, P]),
     "unetk_loss_pixgrad_bwd": (I, [P, P, P, I, I, I, I, I, P, P, P, P, F, F, I, P, I, P]),
     "unetk_loss_spectral_bwd": (I, [P, P, I, I, I, F, P, F, P, P, P]),
+    "unetk_tile_valid": (I, [P, I, I, I, I, I, I, I, P, P]),
+    "unetk_tile_gather": (I, [P, I, I, I, P, I, I, P, I, I, P]),
+    "unetk_blend_accumulate": (I, [P, P, P, I, I, I, I, I, I, P, P, I, I, I, I, P]),
+    "unetk_blend_normalize": (I, [P, P, P, L, P]),
 }
 
 _lib = None

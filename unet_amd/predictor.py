@@ -1,0 +1,195 @@
+"""Sliding-window large-area prediction with Gaussian-weighted blending, on the GPU.
+
+Drop-in for the reference ``LargeAreaPredictor`` hot path (large_area_predictor.py:57-81, 133-219):
+``create_gaussian_weight_kernel(P)`` and ``predict_large_area(model, features)``.  The features are
+uploaded once; tile validity, the batched tile gather, the network and the blend all run on the
+device.  Tile order, NaN handling, the fp32 accumulation order and the final division reproduce
+the reference bit for bit given the same per-tile predictions.
+
+With ``torch.distributed`` initialised the tile rows are split into contiguous bands, one per
+rank; a rank receives the partially accumulated overlap strip from the rank above it, adds its own
+tiles in order and passes its own bottom strip on, which keeps the single-process order (and bits).
+"""
+import os
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import call, ptr, stream, dtype_code
+
+FEATURE_VARS = ("GA", "DOV_EW", "DOV_NS", "VGG")    # large_area_predictor.py:161
+
+
+class LargeAreaPredictionConfig:
+    """Prediction parameters (large_area_predictor.py:26-52); paths are the caller's business."""
+    PATCH_SIZE = 128
+    STRIDE = PATCH_SIZE // 16
+    BATCH_SIZE = 16
+    IN_CHANNELS = 4
+    OUT_CHANNELS = 1
+    INIT_FEATURES = 48
+    OUTPUT_DIR = "./large_area_predictions"
+
+
+def band_partition(nti: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous tile-row bands [lo, hi) per rank, sizes differing by at most one row."""
+    base, extra = divmod(nti, world)
+    out, lo = [], 0
+    for r in range(world):
+        hi = lo + base + (1 if r < extra else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def _feature_array(features, var, lat, lon):
+    da = features[var]
+    if hasattr(da, "values") and not callable(getattr(da, "values")):
+        return np.asarray(da.values, dtype=np.float32)
+    return np.asarray(da.isel(lat=slice(0, lat), lon=slice(0, lon)).values, dtype=np.float32)
+
+
+class HipTileBackend:
+    """The device side of the tiled predictor: four libunetk kernels and the UNet eval engine."""
+
+    def valid(self, feats, P, S, nti, ntj):
+        nvar, lat, lon = feats.shape
+        v = torch.empty(nti * ntj, dtype=torch.int32, device=feats.device)
+        call("unetk_tile_valid", ptr(feats), nvar, lat, lon, P, S, nti, ntj, ptr(v), stream())
+        return v.cpu().numpy().astype(bool)
+
+    def make_engine(self, model):
+        from .unet import EvalEngine
+        return EvalEngine(model), model.compute_dtype
+
+    def gather(self, feats, pos_d, first, n, P, dt):
+        nvar, lat, lon = feats.shape
+        ld = ops.pad_channels(nvar, dt)
+        batch = torch.empty((n, P, P, ld), dtype=dt, device=feats.device)
+        call("unetk_tile_gather", ptr(feats), nvar, lat, lon, ptr(pos_d[first:]), n, P, ptr(batch), ld,
+             dtype_code(dt), stream())
+        return batch
+
+    def accumulate(self, out, wk, slot, t0, t1, nti, ntj, P, S, acc, cnt, r0, r1):
+        lat, lon = acc.shape
+        call("unetk_blend_accumulate", ptr(out), ptr(wk), ptr(slot), t0, t1, nti, ntj, P, S, ptr(acc), ptr(cnt),
+             lat, lon, r0, r1, stream())
+
+    def normalize(self, acc, cnt):
+        out = torch.empty_like(acc)
+        call("unetk_blend_normalize", ptr(acc), ptr(cnt), ptr(out), acc.numel(), stream())
+        return out
+
+
+class LargeAreaPredictor:
+    def __init__(self, config):
+        self.config = config
+        os.makedirs(config.OUTPUT_DIR, exist_ok=True)      # large_area_predictor.py:59
+        # tiles per network launch; any value gives identical results (eval mode is per-sample)
+        self.device_batch = max(int(getattr(config, "DEVICE_BATCH", 64)), 1)
+        self.backend = HipTileBackend()
+        # debugging / test hook: when True the per-tile predictions of the last call are kept as
+        # (positions (n,2) int32, predictions (n,P,P) fp32 on the host)
+        self.keep_tile_predictions = False
+        self.last_tile_predictions = None
+
+    def create_gaussian_weight_kernel(self, patch_size: int) -> np.ndarray:
+        """float64 math on the host, then float32, exactly as large_area_predictor.py:71-81."""
+        y, x = np.ogrid[:patch_size, :patch_size]
+        center = patch_size / 2.0
+        sigma = center * 0.5
+        if sigma <= 0:
+            sigma = 1.0
+        k = np.exp(-0.5 * ((x - (center - 0.5)) ** 2 + (y - (center - 0.5)) ** 2) / sigma ** 2)
+        return k.astype(np.float32)
+
+    # ------------------------------------------------------------------ core
+    def predict_large_area(self, model, features, device: Optional[torch.device] = None) -> np.ndarray:
+        P = int(self.config.PATCH_SIZE)
+        lat, lon = len(features.lat), len(features.lon)
+        if device is None:
+            device = next(model.parameters()).device
+        if device.type != "cuda":
+            raise RuntimeError("LargeAreaPredictor runs on the GPU only (no CPU fallback)")
+        if any(v not in features for v in FEATURE_VARS) or lat < P or lon < P:
+            return np.zeros((lat, lon), np.float32)         # no tile is ever valid (:173-175)
+        feats = torch.from_numpy(np.stack([_feature_array(features, v, lat, lon) for v in FEATURE_VARS]))
+        return self.predict_device(model, feats.to(device).contiguous()).cpu().numpy()
+
+    def predict_device(self, model, feats: torch.Tensor) -> torch.Tensor:
+        """feats: (4, lat, lon) fp32 on the device -> blended (lat, lon) fp32 map on every rank."""
+        import torch.distributed as dist
+        be = self.backend
+        P, S = int(self.config.PATCH_SIZE), int(self.config.STRIDE)
+        nvar, lat, lon = feats.shape
+        dev = feats.device
+        nti, ntj = (lat - P) // S + 1, (lon - P) // S + 1
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        rank = dist.get_rank() if world > 1 else 0
+        if world > nti:
+            raise ValueError(f"{world} ranks for {nti} tile rows: use at most one rank per tile row")
+        bands = band_partition(nti, world)
+        model.eval()
+        engine, dt = be.make_engine(model)
+        wk = torch.from_numpy(self.create_gaussian_weight_kernel(P)).to(dev)
+
+        valid_h = be.valid(feats, P, S, nti, ntj)
+        slot_h = np.full(nti * ntj, -1, np.int32)
+        slot_h[valid_h] = np.arange(int(valid_h.sum()), dtype=np.int32)
+        slot = torch.from_numpy(slot_h).to(dev)
+        tiles = np.flatnonzero(valid_h)                      # lat-major, as the reference loops
+        pos_all = np.stack([(tiles // ntj) * S, (tiles % ntj) * S], 1).astype(np.int32)
+        pos_d = torch.from_numpy(pos_all).to(dev)
+
+        lo_row, hi_row = bands[rank]
+        mine = np.flatnonzero((tiles // ntj >= lo_row) & (tiles // ntj < hi_row))   # consecutive ids
+        acc = torch.zeros((lat, lon), dtype=torch.float32, device=dev)
+        cnt = torch.zeros((lat, lon), dtype=torch.float32, device=dev)
+
+        # the network on this rank's tiles: the expensive part, independent of the blend order
+        preds = []
+        for s in range(0, len(mine), self.device_batch):
+            ids = mine[s:s + self.device_batch]
+            out = engine(be.gather(feats, pos_d, int(ids[0]), len(ids), P, dt))
+            if out.shape[1] != 1:
+                out = out[:, :1].contiguous()
+            preds.append((int(ids[0]), int(ids[-1]) + 1, out))
+
+        # blend.  Rows below lo_row*S may already hold tiles of the ranks above: take their
+        # partial sums first, add this band's tiles in order, hand the bottom strip on.
+        row0 = lo_row * S
+        row1 = min((hi_row - 1) * S + P, lat)
+        if rank > 0:
+            strip_end = min((bands[rank - 1][1] - 1) * S + P, lat)
+            if strip_end > row0:
+                buf = torch.empty((2, strip_end - row0, lon), dtype=torch.float32, device=dev)
+                dist.recv(buf, src=rank - 1)
+                acc[row0:strip_end] = buf[0]
+                cnt[row0:strip_end] = buf[1]
+                row1 = max(row1, strip_end)
+        for t0, t1, out in preds:
+            r0 = int(pos_all[t0, 0])
+            r1 = min(int(pos_all[t1 - 1, 0]) + P, lat)
+            be.accumulate(out, wk, slot, t0, t1, nti, ntj, P, S, acc, cnt, r0, r1)
+        if rank < world - 1:
+            nxt_row0 = hi_row * S
+            send_end = min((hi_row - 1) * S + P, lat)
+            if send_end > nxt_row0:
+                dist.send(torch.stack([acc[nxt_row0:send_end], cnt[nxt_row0:send_end]]).contiguous(),
+                          dst=rank + 1)
+        if self.keep_tile_predictions:
+            kept = [o[:, 0].float().cpu().numpy() for _, _, o in preds]
+            ids = np.concatenate([np.arange(a, b) for a, b, _ in preds]) if preds else np.zeros(0, np.int64)
+            self.last_tile_predictions = (pos_all[ids], np.concatenate(kept) if kept else np.zeros((0, P, P), np.float32))
+        out_map = be.normalize(acc, cnt)
+        if world == 1:
+            return out_map
+        # rank r owns the rows from its band's first row to the next band's first row (last: to the end)
+        own0 = row0 if rank > 0 else 0
+        own1 = bands[rank + 1][0] * S if rank < world - 1 else lat
+        full = torch.zeros((lat, lon), dtype=torch.float32, device=dev)
+        full[own0:own1] = out_map[own0:own1]
+        dist.all_reduce(full)            # disjoint row ownership: the sum only assembles the map
+        return full

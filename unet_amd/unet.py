@@ -105,28 +105,46 @@ def _pack_all(model, dt, transpose):
     return packed
 
 
-def _eval_forward(model, x):
-    """Inference path: BatchNorm folded into the convolution epilogue, no Dropout."""
-    dt = model.compute_dtype
-    pk = _pack_all(model, dt, False)
-    h = ops.nchw_to_nhwc(x, dt)
+class EvalEngine:
+    """Inference path with BatchNorm folded into the convolution epilogues and Dropout off.
 
-    def block(name, t):
-        seq = getattr(model, name)
-        for ci, bi in ((0, 1), (3, 4)):
-            bn = seq[bi]
-            sc, sh = ops.bn_fold_eval(bn.weight, bn.bias, bn.running_mean, bn.running_var, None, bn.eps)
-            t, _ = ops.conv_fwd(t, pk[(name, ci)], scale=sc, shift=sh, act=1)
+    Packs the weights and folds the running statistics once; ``__call__`` takes an NHWC batch in
+    the compute dtype and returns the (B,out,H,W) fp32 prediction.  Rebuild after changing weights.
+    """
+
+    def __init__(self, model):
+        self.model = model
+        self.dt = model.compute_dtype
+        self.pk = _pack_all(model, self.dt, False)
+        self.fold = {}
+        for name in BLOCKS:
+            seq = getattr(model, name)
+            for ci, bi in ((0, 1), (3, 4)):
+                bn = seq[bi]
+                self.fold[(name, ci)] = ops.bn_fold_eval(bn.weight, bn.bias, bn.running_mean,
+                                                         bn.running_var, None, bn.eps)
+        self.head_w = model.conv.weight.detach()
+        self.head_b = model.conv.bias.detach() if model.conv.bias is not None else None
+
+    def _block(self, name, t):
+        for ci in (0, 3):
+            sc, sh = self.fold[(name, ci)]
+            t, _ = ops.conv_fwd(t, self.pk[(name, ci)], scale=sc, shift=sh, act=1)
         return t
 
-    e1 = block("encoder1", h)
-    e2 = block("encoder2", ops.maxpool2x2(e1))
-    e3 = block("encoder3", ops.maxpool2x2(e2))
-    e4 = block("encoder4", ops.maxpool2x2(e3))
-    d = block("bottleneck", ops.maxpool2x2(e4))
-    for name, skip in (("decoder4", e4), ("decoder3", e3), ("decoder2", e2), ("decoder1", e1)):
-        d = block(name, ops.upsample_concat(d, skip))
-    return ops.head1x1_fwd(d, model.conv.weight, model.conv.bias)
+    def __call__(self, h):
+        e1 = self._block("encoder1", h)
+        e2 = self._block("encoder2", ops.maxpool2x2(e1))
+        e3 = self._block("encoder3", ops.maxpool2x2(e2))
+        e4 = self._block("encoder4", ops.maxpool2x2(e3))
+        d = self._block("bottleneck", ops.maxpool2x2(e4))
+        for name, skip in (("decoder4", e4), ("decoder3", e3), ("decoder2", e2), ("decoder1", e1)):
+            d = self._block(name, ops.upsample_concat(d, skip))
+        return ops.head1x1_fwd(d, self.head_w, self.head_b)
+
+
+def _eval_forward(model, x):
+    return EvalEngine(model)(ops.nchw_to_nhwc(x, model.compute_dtype))
 
 
 class _UNetTrainFn(torch.autograd.Function):
