@@ -150,6 +150,46 @@ int unetk_blend_accumulate(const float* pred, const float* wk, const int* slot, 
 /* out = acc / (cnt > 1e-9 ? cnt : 1)  (:215-216) */
 int unetk_blend_normalize(const float* acc, const float* cnt, float* out, int64_t n, unetk_stream_t stream);
 
+/* ---- Swin-UNet pieces -------------------------------------------------------------------
+ * Tokens are (B,H,W,C) NHWC.  nn.LayerNorm: swin_unet_model.py:289,295,384,562. */
+int unetk_layernorm_fwd(const void* x, void* y, const float* gamma, const float* beta, float* mean, float* rstd,
+                        int64_t ntok, int C, float eps, int dtype, unetk_stream_t stream);
+int unetk_token_reduce_num_partials(int64_t ntok);
+/* dx = LN'(dy) + add (add nullable: the residual path's gradient); partials: [num_partials][2][C] */
+int unetk_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                        const void* add, void* dx, float* dgamma, float* dbeta, float* partials, int64_t ntok,
+                        int C, int dtype, unetk_stream_t stream);
+/* bias gradients of the linears: out[c] = sum over tokens */
+int unetk_channel_sum(const void* x, int ld, int64_t ntok, int C, float* out, float* partials, int dtype,
+                      unetk_stream_t stream);
+/* nn.GELU (erf form), swin_unet_model.py:299 */
+int unetk_gelu_fwd(const void* x, void* y, int64_t n, int dtype, unetk_stream_t stream);
+int unetk_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, int dtype, unetk_stream_t stream);
+/* DropPath scale per sample (:139-148) with optional add: y = x*keep[b] + add */
+int unetk_scale_sample(const void* x, const float* keep, const void* add, void* y, int B, int64_t per_sample,
+                       int dtype, unetk_stream_t stream);
+/* patch embedding gather for Conv2d(k=ps, s=ps) (:559-560, 634): NCHW fp32 -> (B,H/ps,W/ps,ld) */
+int unetk_patchify(const float* x, void* tok, int B, int Cin, int H, int W, int ps, int ld, int dtype,
+                   unetk_stream_t stream);
+int unetk_unpatchify(const void* dtok, float* dx, int B, int Cin, int H, int W, int ps, int ld, int dtype,
+                     unetk_stream_t stream);
+/* PatchMerging 2x2 gather, concat order (0,0)(1,0)(0,1)(1,1), zero pad for odd sizes (:396-417);
+ * backward=1: x is the gradient of the merged (B,ceil(H/2),ceil(W/2),4C) tensor, out that of the input */
+int unetk_merge_gather(const void* x, void* out, int B, int H, int W, int C, int backward, int dtype,
+                       unetk_stream_t stream);
+/* ConvTranspose2d(k=2,s=2) (:501,521) = GEMM to (B,h,w,4*Co) then this shuffle (+bias) into channels
+ * [0,Co) of the (B,2h,2w,ldcat) concat buffer; backward=1 gathers the gradient back into tmp */
+int unetk_pixel_shuffle(void* tmp, void* cat, int ldcat, const float* bias, int B, int h, int w, int Co,
+                        int backward, int dtype, unetk_stream_t stream);
+/* WindowAttention + cyclic shift + window partition/reverse (:161-200, 241-269, 339-360), window 8,
+ * head dim 32.  qkv: (B,He,We,3C) from the qkv linear; out: (B,He,We,C) before the proj linear.
+ * table: relative_position_bias_table (225, heads) fp32. */
+int unetk_window_attn_fwd(const void* qkv, void* out, const float* table, int B, int He, int We, int C, int heads,
+                          int shift, int use_mask, float scale, int dtype, unetk_stream_t stream);
+int unetk_window_attn_bwd(const void* qkv, const void* dout, void* dqkv, const float* table, float* dtable,
+                          float* dtable_partials, int B, int He, int We, int C, int heads, int shift, int use_mask,
+                          float scale, int dtype, unetk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

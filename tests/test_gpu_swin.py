@@ -1,0 +1,214 @@
+"""GPU parity of the Swin-UNet kernels and of unet_amd.SwinUNet against the CPU oracle and goldens.
+
+float32: outputs 1e-4 relative L2 (the stated bound).  Gradients are compared with the float64
+oracle: with batch statistics over a handful of elements in the decoder the fp32 gradients of the
+reference itself carry ~5e-3 of rounding noise (see tests/golden/make_golden.py), so the whole-model
+gradient bound is 2e-2 while every kernel is pinned on its own at 1e-4.
+bfloat16: single kernels 2e-2; the whole model in eval mode is printed and bounded at 5e-2 (bf16
+storage of a 12-block transformer plus an 9-conv decoder; the fp32 path is the parity reference).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import swin_oracle
+from oracle import weights as W
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 1e-4, torch.bfloat16: 2e-2}
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).detach().double().cpu().reshape(-1)
+    b = torch.as_tensor(b).detach().double().cpu().reshape(-1)
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def rnd(shape, seed, dt, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dt).float()
+
+
+def sub(t, n):
+    f = torch.as_tensor(t).detach().reshape(-1)
+    step = max(1, f.numel() // n)
+    return f[::step][:n].float().cpu().numpy()
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("C", [96, 384, 1536])
+def test_layernorm_fwd_bwd(dt, C):
+    from unet_amd import ops
+    x = rnd((2, 5, 7, C), 1, dt) * 1.3 + 0.2
+    x = x.to(dt).float()
+    g, b = torch.rand(C) + 0.5, torch.randn(C) * 0.1
+    dy = rnd((2, 5, 7, C), 2, dt)
+    add = rnd((2, 5, 7, C), 3, dt)
+    xr, gr, br = x.clone().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (C,), gr, br)
+    ref.backward(dy)
+    y, mean, rstd = ops.layernorm_fwd(x.to("cuda", dt), g.cuda(), b.cuda())
+    assert rel(y, ref) < TOL[dt]
+    dx, dg, db = ops.layernorm_bwd(dy.to("cuda", dt), x.to("cuda", dt), g.cuda(), mean, rstd, add=add.to("cuda", dt))
+    assert rel(dx, xr.grad + add) < TOL[dt]
+    assert rel(dg, gr.grad) < TOL[dt] and rel(db, br.grad) < TOL[dt]
+    assert rel(ops.channel_sum(dy.to("cuda", dt)), dy.sum((0, 1, 2))) < 1e-5
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_gelu_scale_merge_shuffle(dt):
+    from unet_amd import ops
+    x = rnd((3, 6, 5, 64), 4, dt) * 2
+    xr = x.clone().requires_grad_(True)
+    ref = F.gelu(xr)
+    dy = rnd(tuple(x.shape), 5, dt)
+    ref.backward(dy)
+    xd = x.to("cuda", dt)
+    assert rel(ops.gelu_fwd(xd), ref) < TOL[dt]
+    assert rel(ops.gelu_bwd(dy.to("cuda", dt), xd), xr.grad) < TOL[dt]
+    keep = torch.tensor([0.0, 1.25, 1.25])
+    assert rel(ops.scale_sample(xd, keep.cuda(), xd), x * keep.view(3, 1, 1, 1) + x) < TOL[dt]
+    # patch merging gather, odd sizes (zero pad) and its inverse
+    s = x
+    sp = F.pad(s, (0, 0, 0, 5 % 2, 0, 6 % 2))
+    want = torch.cat([sp[:, 0::2, 0::2], sp[:, 1::2, 0::2], sp[:, 0::2, 1::2], sp[:, 1::2, 1::2]], -1)
+    got = ops.merge_gather(xd)
+    assert torch.equal(got.float().cpu(), want)
+    back = ops.merge_scatter(got, 6, 5)
+    assert torch.equal(back.float().cpu(), x)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("case", [(2, 16, 24, 3, 0), (2, 16, 24, 3, 4), (1, 8, 8, 6, 4), (1, 32, 8, 12, 4)])
+def test_window_attention_fwd_bwd(dt, case):
+    """Shifted and unshifted windows, the single-window stage (mask still applied), several heads."""
+    from unet_amd import ops
+    B, H, Wd, heads, shift = case
+    C = heads * 32
+    sd = {"qkv.weight": torch.zeros(3 * C, C), "qkv.bias": torch.zeros(3 * C), "proj.weight": torch.eye(C),
+          "proj.bias": torch.zeros(C),
+          "relative_position_bias_table": rnd((225, heads), 6, torch.float32, 0.5),
+          "relative_position_index": swin_oracle.relative_position_index(8)}
+    qkv = rnd((B, H, Wd, 3 * C), 7, dt, 0.8)
+    dout = rnd((B, H, Wd, C), 8, dt)
+    mask = swin_oracle.shift_mask(H, Wd, 8)
+
+    def ref_attn(qkv_t, table):
+        # the oracle's attention on pre-computed qkv: identity qkv/proj weights are bypassed by hand
+        h = qkv_t
+        if shift:
+            h = torch.roll(h, (-shift, -shift), (1, 2))
+        wins = swin_oracle._partition(h, 8)
+        Bn, N, _ = wins.shape
+        q, k, v = wins.view(Bn, N, 3, heads, 32).permute(2, 0, 3, 1, 4)
+        a = (q * 32 ** -0.5) @ k.transpose(-2, -1)
+        bias = table[sd["relative_position_index"].view(-1)].view(N, N, heads).permute(2, 0, 1)
+        a = a + bias.unsqueeze(0)
+        nW = mask.shape[0]
+        a = (a.view(Bn // nW, nW, heads, N, N) + mask[None, :, None]).view(-1, heads, N, N).softmax(-1)
+        y = (a @ v).transpose(1, 2).reshape(Bn, N, C)
+        y = swin_oracle._unpartition(y, 8, H, Wd)
+        if shift:
+            y = torch.roll(y, (shift, shift), (1, 2))
+        return y
+
+    qr = qkv.double().requires_grad_(True)
+    tr_ = sd["relative_position_bias_table"].double().requires_grad_(True)
+    ref = ref_attn(qr, tr_)
+    ref.backward(dout.double())
+    table = sd["relative_position_bias_table"].cuda()
+    out = ops.window_attn_fwd(qkv.to("cuda", dt), table, heads, shift, True)
+    assert rel(out, ref) < TOL[dt]
+    dqkv, dtable = ops.window_attn_bwd(qkv.to("cuda", dt), dout.to("cuda", dt), table, heads, shift, True)
+    assert rel(dqkv, qr.grad) < TOL[dt] * (2 if dt == torch.bfloat16 else 1)
+    assert rel(dtable, tr_.grad) < TOL[dt] * (2 if dt == torch.bfloat16 else 1)
+
+
+def build(dt):
+    from unet_amd.swin import SwinUNet
+    cfg = dict(swin_oracle.DEFAULT_CONFIG)
+    sd = W.fill_state_dict(swin_oracle.swin_template(cfg), seed=42)
+    m = SwinUNet(cfg, compute_dtype=dt)
+    m.load_state_dict(sd)
+    return m.cuda(), sd, cfg
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("name,B,H,Wd", [("s64", 2, 64, 64), ("s128x64", 1, 128, 64), ("s256", 1, 256, 256)])
+def test_swin_eval_forward(golden, dt, name, B, H, Wd):
+    m, sd, cfg = build(dt)
+    m.eval()
+    x, _, _ = W.synthetic_batch(B, 4, H, Wd, seed=42)
+    out = m(x.cuda())
+    ref, _ = swin_oracle.swin_unet_forward(sd, x, cfg, False)
+    assert out.shape == ref.shape == (B, 1, H // 2, Wd // 2)
+    e = rel(out, ref)
+    print(f"swin eval {name} {dt}: rel {e:.2e}")
+    assert e < (1e-4 if dt == torch.float32 else 5e-2)
+    if dt == torch.float32:
+        assert rel(sub(out, 16384), golden("swin")[f"{name}.eval_out"]) < 1e-4
+
+
+@pytest.mark.parametrize("name,B,H,Wd", [("s64", 2, 64, 64), ("s128x64", 1, 128, 64)])
+def test_swin_train_forward_backward_fp32(golden, name, B, H, Wd):
+    g = golden("swin")
+    m, sd, cfg = build(torch.float32)
+    m.train()
+    m.drop_path_override = [[None, None]] * sum(cfg["depths"])
+    x, y, _ = W.synthetic_batch(B, 4, H, Wd, seed=42)
+    xd = x.cuda().requires_grad_(True)
+    out = m(xd)
+    tgt = F.avg_pool2d(y, 2)
+    loss = ((out - tgt.cuda()) ** 2).mean()
+    loss.backward()
+    torch.cuda.synchronize()
+    assert rel(sub(out, 16384), g[f"{name}.train_out"]) < 1e-4
+    assert abs(loss.item() - float(g[f"{name}.loss"])) < 1e-4 * float(g[f"{name}.loss"])
+    # float64 oracle gradients
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    params = {k: v.clone().requires_grad_(True) for k, v in sd64.items() if v.is_floating_point() and "running_" not in k}
+    full = dict(sd64)
+    full.update(params)
+    xo = x.double().requires_grad_(True)
+    o_out, o_stats = swin_oracle.swin_unet_forward(full, xo, cfg, True, None)
+    ((o_out - tgt.double()) ** 2).mean().backward()
+    names = [n for n, _ in m.named_parameters() if n != "final_conv.0.bias"]
+    mine = torch.cat([dict(m.named_parameters())[n].grad.double().cpu().reshape(-1) for n in names])
+    want = torch.cat([params[n].grad.reshape(-1) for n in names])
+    worst = max((rel(dict(m.named_parameters())[n].grad, params[n].grad), n) for n in names)
+    e_all, e_in = rel(mine, want), rel(xd.grad, xo.grad)
+    print(f"swin train {name}: out {rel(out, o_out):.2e} grads(all) {e_all:.2e} worst {worst[0]:.2e} {worst[1]} dx {e_in:.2e}")
+    assert rel(out, o_out) < 1e-4
+    assert e_all < 2e-2 and e_in < 2e-2 and worst[0] < 1e-1, (e_all, e_in, worst)
+    assert float(m.final_conv[0].bias.grad.abs().max()) == 0.0
+    norms = np.array([p.grad.double().norm().item() for n, p in m.named_parameters()])
+    keep = np.array([n != "final_conv.0.bias" for n, _ in m.named_parameters()])
+    assert rel(norms[keep], g[f"{name}.grad_norms"][keep]) < 2e-2
+    msd = m.state_dict()
+    for k, v in o_stats.items():
+        assert rel(msd[k], v) < 1e-4, k
+
+
+def test_swin_seeded_droppath_and_errors(golden):
+    m, sd, cfg = build(torch.float32)
+    m.train()
+    x, _, _ = W.synthetic_batch(2, 4, 64, 64, seed=42)
+    torch.manual_seed(99)
+    dp = swin_oracle.draw_drop_path(cfg, 2)
+    m.drop_path_override = dp
+    out = m(x.cuda())
+    assert rel(sub(out, 16384), golden("swin")["s64.droppath_seed99_out"]) < 1e-4
+    m.drop_path_override = None
+    draws = m._draw_drop_path(512, torch.device("cuda"))
+    assert draws[0] == [None, None]
+    last = draws[-1][0]
+    assert torch.all((last == 0) | ((last - 1 / 0.9).abs() < 1e-5)) and 0.05 < (last == 0).float().mean() < 0.15
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 4, 96, 160, device="cuda"))        # 12x20 tokens at stage 1: not window multiples
+    with pytest.raises(RuntimeError):
+        m.cpu()(torch.zeros(1, 4, 64, 64))
+    from unet_amd.swin import SwinUNet
+    with pytest.raises(ValueError):
+        SwinUNet(dict(cfg, window_size=7))

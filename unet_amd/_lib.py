@@ -61,6 +61,19 @@ _SIGNATURES = {
     "unetk_tile_gather": (I, [P, I, I, I, P, I, I, P, I, I, P]),
     "unetk_blend_accumulate": (I, [P, P, P, I, I, I, I, I, I, P, P, I, I, I, I, P]),
     "unetk_blend_normalize": (I, [P, P, P, L, P]),
+    "unetk_layernorm_fwd": (I, [P, P, P, P, P, P, L, I, F, I, P]),
+    "unetk_token_reduce_num_partials": (I, [L]),
+    "unetk_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, L, I, I, P]),
+    "unetk_channel_sum": (I, [P, I, L, I, P, P, I, P]),
+    "unetk_gelu_fwd": (I, [P, P, L, I, P]),
+    "unetk_gelu_bwd": (I, [P, P, P, L, I, P]),
+    "unetk_scale_sample": (I, [P, P, P, P, I, L, I, P]),
+    "unetk_patchify": (I, [P, P, I, I, I, I, I, I, I, P]),
+    "unetk_unpatchify": (I, [P, P, I, I, I, I, I, I, I, P]),
+    "unetk_merge_gather": (I, [P, P, I, I, I, I, I, I, P]),
+    "unetk_pixel_shuffle": (I, [P, P, I, P, I, I, I, I, I, I, P]),
+    "unetk_window_attn_fwd": (I, [P, P, P, I, I, I, I, I, I, I, F, I, P]),
+    "unetk_window_attn_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, F, I, P]),
 }
 
 _lib = None

@@ -1,0 +1,875 @@
+// Swin-UNet specific kernels (gfx950): LayerNorm, GELU, shifted-window attention on MFMA,
+// patch embedding / patch merging gathers, the ConvTranspose2d(2,2) pixel shuffle, DropPath scale
+// and per-channel sums.  Arithmetic follows reference swin_unet_model.py:139-535.
+//
+// Tokens are (B, H, W, C) channel-innermost in the compute dtype.  Window attention is one
+// wavefront per (window, head): the cyclic shift, the window partition and its reverse are index
+// arithmetic on the token grid (no copies), the relative-position bias comes from a 225-entry
+// table staged in LDS, and the shift mask (-100 between different regions) is recomputed from the
+// window coordinates.  QK^T and PV (and the five products of the backward) run on MFMA from
+// LDS-staged operands; softmax is done on the accumulator registers.
+#include "common.h"
+#include "mma.h"
+
+namespace {
+
+constexpr int WS = 8;        // window side
+constexpr int NTOK = 64;     // tokens per window
+constexpr int HD = 32;       // head dimension
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+}
+
+// ------------------------------------------------------------------ LayerNorm over channels
+// One wavefront per token.
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
+                                                            float* __restrict__ mean_out,
+                                                            float* __restrict__ rstd_out, long ntok, int C,
+                                                            float eps) {
+  constexpr int E = Vec16<T>::N;
+  const int lane = threadIdx.x & 63;
+  const long tok = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= ntok) return;
+  const T* xr = x + tok * C;
+  float s = 0.f;
+  for (int c = lane * E; c < C; c += 64 * E) {
+    Vec16<T> v = load16(xr + c);
+#pragma unroll
+    for (int e = 0; e < E; ++e) s += to_f32(v.v[e]);
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+  for (int c = lane * E; c < C; c += 64 * E) {
+    Vec16<T> v = load16(xr + c);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const float d = to_f32(v.v[e]) - mean;
+      q += d * d;
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+  for (int c = lane * E; c < C; c += 64 * E) {
+    Vec16<T> v = load16(xr + c);
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      o.v[e] = from_f32<T>((to_f32(v.v[e]) - mean) * rstd * gamma[c + e] + beta[c + e]);
+    store16(y + tok * C + c, o);
+  }
+  if (lane == 0) {
+    mean_out[tok] = mean;
+    rstd_out[tok] = rstd;
+  }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g*xhat)) + add,  g = dy * gamma
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd,
+                                                            const T* __restrict__ add, T* __restrict__ dx,
+                                                            long ntok, int C) {
+  constexpr int E = Vec16<T>::N;
+  const int lane = threadIdx.x & 63;
+  const long tok = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= ntok) return;
+  const float mu = mean[tok], rs = rstd[tok];
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = lane * E; c < C; c += 64 * E) {
+    Vec16<T> dv = load16(dy + tok * C + c), xv = load16(x + tok * C + c);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const float g = to_f32(dv.v[e]) * gamma[c + e];
+      s1 += g;
+      s2 += g * (to_f32(xv.v[e]) - mu) * rs;
+    }
+  }
+  s1 = wave_sum(s1) / (float)C;
+  s2 = wave_sum(s2) / (float)C;
+  for (int c = lane * E; c < C; c += 64 * E) {
+    Vec16<T> dv = load16(dy + tok * C + c), xv = load16(x + tok * C + c);
+    Vec16<T> av = zero16<T>();
+    if (add != nullptr) av = load16(add + tok * C + c);
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const float g = to_f32(dv.v[e]) * gamma[c + e];
+      const float xh = (to_f32(xv.v[e]) - mu) * rs;
+      o.v[e] = from_f32<T>(rs * (g - s1 - xh * s2) + (add ? to_f32(av.v[e]) : 0.f));
+    }
+    store16(dx + tok * C + c, o);
+  }
+}
+
+// Per-channel sums over tokens.  MODE 0: s0 = sum x.  MODE 1: s0 = sum dy*xhat, s1 = sum dy (LayerNorm).
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void token_reduce_kernel(const T* __restrict__ a, int lda,
+                                                           const T* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, long ntok, int C,
+                                                           int CS, int chunk, float* __restrict__ partials) {
+  // blockIdx.y selects a slab of CS channels (CS/E <= 256 channel groups per workgroup)
+  constexpr int E = Vec16<T>::N;
+  __shared__ float red[2][256 * E];
+  const int CG = CS / E;
+  const int lanes = 256 / CG;
+  const int tid = threadIdx.x;
+  const int cg = tid % CG, pl = tid / CG;
+  const int cbase = blockIdx.y * CS;
+  const int c0 = cbase + cg * E;
+  float s0[E], s1[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) s0[e] = s1[e] = 0.f;
+  if (pl < lanes) {
+    const long pbeg = (long)blockIdx.x * chunk;
+    long pend = pbeg + chunk;
+    if (pend > ntok) pend = ntok;
+    for (long p = pbeg + pl; p < pend; p += lanes) {
+      Vec16<T> av = load16(a + p * lda + c0);
+      if (MODE == 0) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) s0[e] += to_f32(av.v[e]);
+      } else {
+        Vec16<T> xv = load16(x + p * C + c0);
+        const float mu = mean[p], rs = rstd[p];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const float d = to_f32(av.v[e]);
+          s0[e] += d * (to_f32(xv.v[e]) - mu) * rs;
+          s1[e] += d;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    red[0][tid * E + e] = s0[e];
+    red[1][tid * E + e] = s1[e];
+  }
+  __syncthreads();
+  for (int c = tid; c < CS; c += 256) {
+    const int g = c / E, e = c - g * E;
+    float t0 = 0.f, t1 = 0.f;
+    for (int l = 0; l < lanes; ++l) {
+      t0 += red[0][(l * CG + g) * E + e];
+      t1 += red[1][(l * CG + g) * E + e];
+    }
+    partials[((long)blockIdx.x * 2) * C + cbase + c] = t0;
+    partials[((long)blockIdx.x * 2 + 1) * C + cbase + c] = t1;
+  }
+}
+
+__global__ __launch_bounds__(256) void partial_sum2_kernel(const float* __restrict__ partials, int nparts, int C,
+                                                           float* out0, float* out1) {
+  __shared__ double red[2][64][4];
+  const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;
+  const int c = blockIdx.x * 4 + cl;
+  double s = 0.0, q = 0.0;
+  if (c < C)
+    for (int r = rl; r < nparts; r += 64) {
+      s += (double)partials[((long)r * 2) * C + c];
+      q += (double)partials[((long)r * 2 + 1) * C + c];
+    }
+  red[0][rl][cl] = s;
+  red[1][rl][cl] = q;
+  __syncthreads();
+  if (threadIdx.x < 4 && blockIdx.x * 4 + threadIdx.x < C) {
+    const int cc = blockIdx.x * 4 + threadIdx.x;
+    double ss = 0.0, qq = 0.0;
+    for (int r = 0; r < 64; ++r) {
+      ss += red[0][r][threadIdx.x];
+      qq += red[1][r][threadIdx.x];
+    }
+    if (out0) out0[cc] = (float)ss;
+    if (out1) out1[cc] = (float)qq;
+  }
+}
+
+// ------------------------------------------------------------------ elementwise
+template <typename T>
+__global__ void gelu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long nvec) {
+  constexpr int E = Vec16<T>::N;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nvec) return;
+  Vec16<T> v = load16(x + i * E), o;
+#pragma unroll
+  for (int e = 0; e < E; ++e) o.v[e] = from_f32<T>(gelu_f(to_f32(v.v[e])));
+  store16(y + i * E, o);
+}
+
+template <typename T>
+__global__ void gelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, T* __restrict__ dx, long nvec) {
+  constexpr int E = Vec16<T>::N;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nvec) return;
+  Vec16<T> d = load16(dy + i * E), v = load16(x + i * E), o;
+#pragma unroll
+  for (int e = 0; e < E; ++e) o.v[e] = from_f32<T>(to_f32(d.v[e]) * gelu_grad(to_f32(v.v[e])));
+  store16(dx + i * E, o);
+}
+
+// y = x * keep[b]  (+ add)
+template <typename T>
+__global__ void scale_sample_kernel(const T* __restrict__ x, const float* __restrict__ keep,
+                                    const T* __restrict__ add, T* __restrict__ y, long nvec, long vec_per_sample) {
+  constexpr int E = Vec16<T>::N;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nvec) return;
+  const float k = keep ? keep[i / vec_per_sample] : 1.f;
+  Vec16<T> v = load16(x + i * E), o;
+  Vec16<T> a = zero16<T>();
+  if (add) a = load16(add + i * E);
+#pragma unroll
+  for (int e = 0; e < E; ++e) o.v[e] = from_f32<T>(to_f32(v.v[e]) * k + (add ? to_f32(a.v[e]) : 0.f));
+  store16(y + i * E, o);
+}
+
+// ------------------------------------------------------------------ gathers
+// tokens[b,yp,xp, c*ps*ps + ky*ps + kx] = x[b,c,ps*yp+ky,ps*xp+kx]   (x NCHW fp32)
+template <typename T>
+__global__ void patchify_kernel(const float* __restrict__ x, T* __restrict__ tok, int B, int Cin, int H, int W,
+                                int ps, int Hp, int Wp, int ld) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * Hp * Wp * ld;
+  if (idx >= total) return;
+  const int k = idx % ld;
+  long p = idx / ld;
+  const int xp = p % Wp;
+  p /= Wp;
+  const int yp = p % Hp;
+  const int b = p / Hp;
+  float v = 0.f;
+  if (k < Cin * ps * ps) {
+    const int c = k / (ps * ps), r = k - c * ps * ps;
+    const int ky = r / ps, kx = r - ky * ps;
+    v = x[(((long)b * Cin + c) * H + ps * yp + ky) * W + ps * xp + kx];
+  }
+  tok[idx] = from_f32<T>(v);
+}
+
+template <typename T>
+__global__ void unpatchify_kernel(const T* __restrict__ dtok, float* __restrict__ dx, int B, int Cin, int H, int W,
+                                  int ps, int Hp, int Wp, int ld) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * Cin * H * W;
+  if (idx >= total) return;
+  const int xx = idx % W;
+  long p = idx / W;
+  const int yy = p % H;
+  p /= H;
+  const int c = p % Cin;
+  const int b = p / Cin;
+  float v = 0.f;
+  const int yp = yy / ps, xp = xx / ps;
+  if (yp < Hp && xp < Wp)
+    v = to_f32(dtok[(((long)b * Hp + yp) * Wp + xp) * ld + c * ps * ps + (yy % ps) * ps + (xx % ps)]);
+  dx[idx] = v;
+}
+
+// out[b,y2,x2, q*C + c] = x[b, 2*y2 + (q&1), 2*x2 + (q>>1), c]  (zero outside: odd H/W padding)
+template <typename T>
+__global__ void merge_gather_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int H, int W, int C) {
+  constexpr int E = Vec16<T>::N;
+  const int H2 = (H + 1) / 2, W2 = (W + 1) / 2, CG = C / E;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)B * H2 * W2 * 4 * CG) return;
+  const int cg = idx % CG;
+  long p = idx / CG;
+  const int q = p % 4;
+  p /= 4;
+  const int x2 = p % W2;
+  p /= W2;
+  const int y2 = p % H2;
+  const int b = p / H2;
+  const int yy = 2 * y2 + (q & 1), xx = 2 * x2 + (q >> 1);
+  Vec16<T> v = zero16<T>();
+  if (yy < H && xx < W) v = load16(x + (((long)b * H + yy) * W + xx) * C + cg * E);
+  store16(out + ((((long)b * H2 + y2) * W2 + x2) * 4 + q) * C + cg * E, v);
+}
+
+template <typename T>
+__global__ void merge_scatter_kernel(const T* __restrict__ dout, T* __restrict__ dx, int B, int H, int W, int C) {
+  constexpr int E = Vec16<T>::N;
+  const int H2 = (H + 1) / 2, W2 = (W + 1) / 2, CG = C / E;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)B * H * W * CG) return;
+  const int cg = idx % CG;
+  long p = idx / CG;
+  const int xx = p % W;
+  p /= W;
+  const int yy = p % H;
+  const int b = p / H;
+  const int q = (xx & 1) * 2 + (yy & 1);
+  store16(dx + (((long)b * H + yy) * W + xx) * C + cg * E,
+          load16(dout + ((((long)b * H2 + (yy >> 1)) * W2 + (xx >> 1)) * 4 + q) * C + cg * E));
+}
+
+// ConvTranspose2d(k=2,s=2) after its GEMM: tmp[b,y,x,(ky*2+kx)*Co+co] (+bias) -> cat[b,2y+ky,2x+kx,co]
+template <typename T, bool BWD>
+__global__ void pixel_shuffle_kernel(T* __restrict__ tmp, T* __restrict__ cat, int ldcat,
+                                     const float* __restrict__ bias, int B, int h, int w, int Co) {
+  constexpr int E = Vec16<T>::N;
+  const int CG = Co / E;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)B * h * w * 4 * CG) return;
+  const int cg = idx % CG;
+  long p = idx / CG;
+  const int k = p % 4;
+  p /= 4;
+  const int x = p % w;
+  p /= w;
+  const int y = p % h;
+  const int b = p / h;
+  T* tp = tmp + ((((long)b * h + y) * w + x) * 4 + k) * Co + cg * E;
+  T* cp = cat + (((long)b * 2 * h + 2 * y + (k >> 1)) * 2 * w + 2 * x + (k & 1)) * ldcat + cg * E;
+  if (BWD) {
+    store16(tp, load16(cp));
+  } else {
+    Vec16<T> v = load16(tp);
+    if (bias != nullptr) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) v.v[e] = from_f32<T>(to_f32(v.v[e]) + bias[cg * E + e]);
+    }
+    store16(cp, v);
+  }
+}
+
+// ------------------------------------------------------------------ window attention
+template <typename T> struct AttnLds {
+  static constexpr int R32 = HD * (int)sizeof(T) + 16;     // row of 32 elements + pad
+  static constexpr int R64 = NTOK * (int)sizeof(T) + 16;   // row of 64 elements + pad
+  static constexpr int C32 = HD * (int)sizeof(T) / 64;     // 64-byte chunks per row
+  static constexpr int C64 = NTOK * (int)sizeof(T) / 64;
+};
+
+struct AttnGeom {
+  int B, He, We, C, heads, shift, use_mask;
+  float scale;
+};
+
+__device__ __forceinline__ int region_of(int s, int extent) {
+  return s < extent - WS ? 0 : (s < extent - WS / 2 ? 1 : 2);
+}
+
+// acc[mt][nt] += A(rows mt*16.., K) * B(rows nt*16.., K)^T with both operands row-major in LDS
+template <typename T, int MT, int NT, int CHUNKS>
+__device__ __forceinline__ void lds_gemm(const char* A, int lda, const char* Bm, int ldb, int lane,
+                                         f32x4 (&acc)[MT][NT]) {
+  using M = MMA<T>;
+#pragma unroll
+  for (int ch = 0; ch < CHUNKS; ++ch)
+#pragma unroll
+    for (int ks = 0; ks < M::KSTEPS; ++ks) {
+      typename M::frag af[MT], bf_[NT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) af[m] = M::load(A + (m * 16 + (lane & 15)) * lda + ch * 64, ks, lane);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) bf_[n] = M::load(Bm + (n * 16 + (lane & 15)) * ldb + ch * 64, ks, lane);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = M::mma(af[m], bf_[n], acc[m][n]);
+    }
+}
+
+// softmax(scale*S + bias + mask) in place on the 64x64 accumulator tile set (C layout)
+__device__ __forceinline__ void window_softmax(f32x4 (&s)[4][4], const float* tbl, const AttnGeom& g, int wy, int wx,
+                                               int lane) {
+  const int cl = lane & 15, pg = lane >> 4;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = mt * 16 + 4 * pg + r;
+      const int yi = i >> 3, xi = i & 7;
+      const int idi = 3 * region_of(wy * WS + yi, g.He) + region_of(wx * WS + xi, g.We);
+      float mx = -INFINITY;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int j = nt * 16 + cl;
+        const int yj = j >> 3, xj = j & 7;
+        float v = s[mt][nt][r] * g.scale + tbl[(yi - yj + WS - 1) * (2 * WS - 1) + (xi - xj + WS - 1)];
+        if (g.use_mask) {
+          const int idj = 3 * region_of(wy * WS + yj, g.He) + region_of(wx * WS + xj, g.We);
+          if (idi != idj) v += -100.0f;
+        }
+        s[mt][nt][r] = v;
+        mx = fmaxf(mx, v);
+      }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const float e = expf(s[mt][nt][r] - mx);
+        s[mt][nt][r] = e;
+        sum += e;
+      }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
+      const float inv = 1.0f / sum;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) s[mt][nt][r] *= inv;
+    }
+}
+
+__device__ __forceinline__ long window_token(const AttnGeom& g, int b, int wy, int wx, int n) {
+  int ty = wy * WS + (n >> 3) + g.shift, tx = wx * WS + (n & 7) + g.shift;
+  if (ty >= g.He) ty -= g.He;
+  if (tx >= g.We) tx -= g.We;
+  return ((long)b * g.He + ty) * g.We + tx;
+}
+
+template <typename T>
+__device__ __forceinline__ void stage_rows(const T* src, char* rows, int ldr, char* tr, int ldt, int n) {
+  // this lane's token: 32 elements -> row n of `rows`, and column n of the transposed image `tr`
+  constexpr int E = Vec16<T>::N;
+#pragma unroll
+  for (int p = 0; p < HD / E; ++p) {
+    Vec16<T> v = load16(src + p * E);
+    if (rows) store16(reinterpret_cast<T*>(rows + n * ldr) + p * E, v);
+    if (tr) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) reinterpret_cast<T*>(tr + (p * E + e) * ldt)[n] = v.v[e];
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void window_attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+                                                             const float* __restrict__ table, AttnGeom g) {
+  using L = AttnLds<T>;
+  __shared__ __attribute__((aligned(16))) char Qs[NTOK * L::R32];
+  __shared__ __attribute__((aligned(16))) char Ks[NTOK * L::R32];
+  __shared__ __attribute__((aligned(16))) char Vt[HD * L::R64];
+  __shared__ __attribute__((aligned(16))) char Ps[NTOK * L::R64];
+  __shared__ float tbl[(2 * WS - 1) * (2 * WS - 1)];
+  const int lane = threadIdx.x;
+  const int nwx = g.We / WS, nwy = g.He / WS;
+  int t = blockIdx.x;
+  const int head = t % g.heads;
+  t /= g.heads;
+  const int wx = t % nwx;
+  t /= nwx;
+  const int wy = t % nwy;
+  const int b = t / nwy;
+  for (int i = lane; i < 225; i += 64) tbl[i] = table[i * g.heads + head];
+  const long tok = window_token(g, b, wy, wx, lane);
+  const T* base = qkv + tok * 3 * g.C + head * HD;
+  stage_rows<T>(base, Qs, L::R32, nullptr, 0, lane);
+  stage_rows<T>(base + g.C, Ks, L::R32, nullptr, 0, lane);
+  stage_rows<T>(base + 2 * g.C, nullptr, 0, Vt, L::R64, lane);
+  __syncthreads();
+  f32x4 s[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) s[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  lds_gemm<T, 4, 4, L::C32>(Qs, L::R32, Ks, L::R32, lane, s);
+  window_softmax(s, tbl, g, wy, wx, lane);
+  const int cl = lane & 15, pg = lane >> 4;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        reinterpret_cast<T*>(Ps + (m * 16 + 4 * pg + r) * L::R64)[n * 16 + cl] = from_f32<T>(s[m][n][r]);
+  __syncthreads();
+  f32x4 o[4][2];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) o[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  lds_gemm<T, 4, 2, L::C64>(Ps, L::R64, Vt, L::R64, lane, o);
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long tk = window_token(g, b, wy, wx, m * 16 + 4 * pg + r);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) out[tk * g.C + head * HD + n * 16 + cl] = from_f32<T>(o[m][n][r]);
+    }
+}
+
+// Backward of one (window, head): recomputes P, then dV = P^T dO, dP = dO V^T,
+// dS = P*(dP - rowsum(dP*P)), dQ = scale*dS K, dK = scale*dS^T Q, and the window's contribution to
+// the relative-position-bias table gradient (225 bins, summed in a fixed order).
+template <typename T>
+__global__ __launch_bounds__(64) void window_attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+                                                             T* __restrict__ dqkv, const float* __restrict__ table,
+                                                             float* __restrict__ dtable_partials, AttnGeom g) {
+  using L = AttnLds<T>;
+  __shared__ __attribute__((aligned(16))) char Qs[NTOK * L::R32];
+  __shared__ __attribute__((aligned(16))) char Ks[NTOK * L::R32];
+  __shared__ __attribute__((aligned(16))) char Vs[NTOK * L::R32];
+  __shared__ __attribute__((aligned(16))) char Ds[NTOK * L::R32];
+  __shared__ __attribute__((aligned(16))) char Qt[HD * L::R64];
+  __shared__ __attribute__((aligned(16))) char Kt[HD * L::R64];
+  __shared__ __attribute__((aligned(16))) char Dt[HD * L::R64];
+  __shared__ __attribute__((aligned(16))) char PA[NTOK * L::R64];   // P^T, later dS
+  __shared__ __attribute__((aligned(16))) char PB[NTOK * L::R64];   // dS^T
+  __shared__ float dSf[NTOK][NTOK + 1];
+  __shared__ float tbl[(2 * WS - 1) * (2 * WS - 1)];
+  const int lane = threadIdx.x;
+  const int cl = lane & 15, pg = lane >> 4;
+  const int nwx = g.We / WS, nwy = g.He / WS;
+  int t = blockIdx.x;
+  const int head = t % g.heads;
+  t /= g.heads;
+  const int wx = t % nwx;
+  t /= nwx;
+  const int wy = t % nwy;
+  const int b = t / nwy;
+  for (int i = lane; i < 225; i += 64) tbl[i] = table[i * g.heads + head];
+  const long tok = window_token(g, b, wy, wx, lane);
+  const T* base = qkv + tok * 3 * g.C + head * HD;
+  stage_rows<T>(base, Qs, L::R32, Qt, L::R64, lane);
+  stage_rows<T>(base + g.C, Ks, L::R32, Kt, L::R64, lane);
+  stage_rows<T>(base + 2 * g.C, Vs, L::R32, nullptr, 0, lane);
+  stage_rows<T>(dout + tok * g.C + head * HD, Ds, L::R32, Dt, L::R64, lane);
+  __syncthreads();
+  f32x4 p[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) p[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  lds_gemm<T, 4, 4, L::C32>(Qs, L::R32, Ks, L::R32, lane, p);
+  window_softmax(p, tbl, g, wy, wx, lane);
+  // P^T -> PA
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        reinterpret_cast<T*>(PA + (n * 16 + cl) * L::R64)[m * 16 + 4 * pg + r] = from_f32<T>(p[m][n][r]);
+  __syncthreads();
+  {   // dV[key][d] = sum_query P^T[key][query] * dO^T[d][query]
+    f32x4 dv[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) dv[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    lds_gemm<T, 4, 2, L::C64>(PA, L::R64, Dt, L::R64, lane, dv);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long tk = window_token(g, b, wy, wx, m * 16 + 4 * pg + r);
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+          dqkv[tk * 3 * g.C + 2 * g.C + head * HD + n * 16 + cl] = from_f32<T>(dv[m][n][r]);
+      }
+  }
+  // dP[query][key] = sum_d dO[query][d] * V[key][d]
+  f32x4 dp[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) dp[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  lds_gemm<T, 4, 4, L::C32>(Ds, L::R32, Vs, L::R32, lane, dp);
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float rs = 0.f;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) rs += dp[m][n][r] * p[m][n][r];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) rs += __shfl_xor(rs, o, 64);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) dp[m][n][r] = p[m][n][r] * (dp[m][n][r] - rs);   // dS
+    }
+  __syncthreads();   // PA (P^T) no longer read
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = m * 16 + 4 * pg + r, j = n * 16 + cl;
+        const float v = dp[m][n][r];
+        reinterpret_cast<T*>(PA + i * L::R64)[j] = from_f32<T>(v);
+        reinterpret_cast<T*>(PB + j * L::R64)[i] = from_f32<T>(v);
+        dSf[i][j] = v;
+      }
+  __syncthreads();
+  {   // dQ[query][d] = scale * sum_key dS[query][key] * K^T[d][key];  dK[key][d] = scale * sum_query dS^T * Q^T
+    f32x4 dq[4][2], dk[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) dq[m][n] = dk[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    lds_gemm<T, 4, 2, L::C64>(PA, L::R64, Kt, L::R64, lane, dq);
+    lds_gemm<T, 4, 2, L::C64>(PB, L::R64, Qt, L::R64, lane, dk);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long tk = window_token(g, b, wy, wx, m * 16 + 4 * pg + r);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          dqkv[tk * 3 * g.C + head * HD + n * 16 + cl] = from_f32<T>(dq[m][n][r] * g.scale);
+          dqkv[tk * 3 * g.C + g.C + head * HD + n * 16 + cl] = from_f32<T>(dk[m][n][r] * g.scale);
+        }
+      }
+  }
+  // bias-table gradient of this (window, head): bin (dy,dx) sums dS[i][j] over yi-yj=dy, xi-xj=dx
+  for (int bin = lane; bin < 225; bin += 64) {
+    const int dy = bin / 15 - 7, dx = bin % 15 - 7;
+    float acc = 0.f;
+    for (int yj = 0; yj < WS; ++yj) {
+      const int yi = yj + dy;
+      if (yi < 0 || yi >= WS) continue;
+      for (int xj = 0; xj < WS; ++xj) {
+        const int xi = xj + dx;
+        if (xi < 0 || xi >= WS) continue;
+        acc += dSf[yi * WS + xi][yj * WS + xj];
+      }
+    }
+    dtable_partials[(long)blockIdx.x * 225 + bin] = acc;
+  }
+}
+
+// dtable[bin][head] = sum over (b, window) of the partials, fixed order
+__global__ __launch_bounds__(64) void dtable_reduce_kernel(const float* __restrict__ partials, int nwin, int heads,
+                                                           float* __restrict__ dtable) {
+  const int bin = blockIdx.x, head = blockIdx.y;
+  float s = 0.f;
+  for (int w = threadIdx.x; w < nwin; w += 64) s += partials[((long)w * heads + head) * 225 + bin];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) dtable[bin * heads + head] = s;
+}
+
+// channels per workgroup slab: the largest divisor split of C with at most 256 vector groups
+inline int slab_channels(int C, int E) {
+  int n = 1;
+  while ((C / n) / E > 256 || C % n != 0 || (C / n) % E != 0) ++n;
+  return C / n;
+}
+
+inline int tok_blocks(long ntok) {
+  long n = (ntok + 63) / 64;
+  if (n > 1024) n = 1024;
+  if (n < 1) n = 1;
+  return (int)n;
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, ...)                       \
+  do {                                               \
+    if ((dtype) == UNETK_BF16) {                     \
+      using T = bf16;                                \
+      __VA_ARGS__;                                   \
+    } else {                                         \
+      using T = float;                               \
+      __VA_ARGS__;                                   \
+    }                                                \
+  } while (0)
+#define CHECK_DT(name, dtype) \
+  UNETK_CHECK_ARG((dtype) == UNETK_F32 || (dtype) == UNETK_BF16, name ": bad dtype %d", (dtype))
+#define VEC_OF(dtype) ((dtype) == UNETK_BF16 ? 8 : 4)
+
+extern "C" {
+
+int unetk_layernorm_fwd(const void* x, void* y, const float* gamma, const float* beta, float* mean, float* rstd,
+                        int64_t ntok, int C, float eps, int dtype, hipStream_t stream) {
+  UNETK_CHECK_ARG(x && y && gamma && beta && mean && rstd && ntok > 0, "layernorm_fwd: bad arguments");
+  CHECK_DT("layernorm_fwd", dtype);
+  UNETK_CHECK_ARG(C % VEC_OF(dtype) == 0, "layernorm_fwd: C=%d not a multiple of %d", C, VEC_OF(dtype));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(layernorm_fwd_kernel<T>, dim3(cdiv(ntok, 4)), dim3(256), 0, stream,
+                                       (const T*)x, (T*)y, gamma, beta, mean, rstd, (long)ntok, C, eps));
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_token_reduce_num_partials(int64_t ntok) { return tok_blocks(ntok); }
+
+/* dx = LN'(dy) + add;  dgamma, dbeta = sums over tokens.  partials: [num_partials][2][C] */
+int unetk_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                        const void* add, void* dx, float* dgamma, float* dbeta, float* partials, int64_t ntok,
+                        int C, int dtype, hipStream_t stream) {
+  UNETK_CHECK_ARG(dy && x && gamma && mean && rstd && dx && partials && ntok > 0, "layernorm_bwd: bad arguments");
+  CHECK_DT("layernorm_bwd", dtype);
+  UNETK_CHECK_ARG(C % VEC_OF(dtype) == 0, "layernorm_bwd: unsupported C=%d", C);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3(cdiv(ntok, 4)), dim3(256), 0, stream,
+                                       (const T*)dy, (const T*)x, gamma, mean, rstd, (const T*)add, (T*)dx,
+                                       (long)ntok, C));
+  UNETK_CHECK_LAUNCH();
+  if (dgamma || dbeta) {
+    const int nb = tok_blocks(ntok);
+    const int chunk = cdiv(ntok, nb);
+    const int CS = slab_channels(C, VEC_OF(dtype));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((token_reduce_kernel<T, 1>), dim3(nb, C / CS), dim3(256), 0, stream,
+                                         (const T*)dy, C, (const T*)x, mean, rstd, (long)ntok, C, CS, chunk,
+                                         partials));
+    UNETK_CHECK_LAUNCH();
+    hipLaunchKernelGGL(partial_sum2_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, partials, nb, C, dgamma, dbeta);
+    UNETK_CHECK_LAUNCH();
+  }
+  return UNETK_OK;
+}
+
+/* out[c] = sum over tokens of x[tok][c]  (bias gradients) */
+int unetk_channel_sum(const void* x, int ld, int64_t ntok, int C, float* out, float* partials, int dtype,
+                      hipStream_t stream) {
+  UNETK_CHECK_ARG(x && out && partials && ntok > 0, "channel_sum: bad arguments");
+  CHECK_DT("channel_sum", dtype);
+  UNETK_CHECK_ARG(C % VEC_OF(dtype) == 0 && ld % VEC_OF(dtype) == 0, "channel_sum: unsupported C=%d ld=%d", C, ld);
+  const int nb = tok_blocks(ntok);
+  const int chunk = cdiv(ntok, nb);
+  const int CS = slab_channels(C, VEC_OF(dtype));
+  DISPATCH_T(dtype, hipLaunchKernelGGL((token_reduce_kernel<T, 0>), dim3(nb, C / CS), dim3(256), 0, stream,
+                                       (const T*)x, ld, (const T*)nullptr, (const float*)nullptr,
+                                       (const float*)nullptr, (long)ntok, C, CS, chunk, partials));
+  UNETK_CHECK_LAUNCH();
+  hipLaunchKernelGGL(partial_sum2_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, partials, nb, C, out,
+                     (float*)nullptr);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_gelu_fwd(const void* x, void* y, int64_t n, int dtype, hipStream_t stream) {
+  UNETK_CHECK_ARG(x && y && n > 0, "gelu_fwd: bad arguments");
+  CHECK_DT("gelu_fwd", dtype);
+  UNETK_CHECK_ARG(n % VEC_OF(dtype) == 0, "gelu_fwd: length not a multiple of the vector width");
+  const long nv = n / VEC_OF(dtype);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(gelu_fwd_kernel<T>, dim3(cdiv(nv, 256)), dim3(256), 0, stream, (const T*)x,
+                                       (T*)y, nv));
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, int dtype, hipStream_t stream) {
+  UNETK_CHECK_ARG(dy && x && dx && n > 0, "gelu_bwd: bad arguments");
+  CHECK_DT("gelu_bwd", dtype);
+  UNETK_CHECK_ARG(n % VEC_OF(dtype) == 0, "gelu_bwd: length not a multiple of the vector width");
+  const long nv = n / VEC_OF(dtype);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(gelu_bwd_kernel<T>, dim3(cdiv(nv, 256)), dim3(256), 0, stream, (const T*)dy,
+                                       (const T*)x, (T*)dx, nv));
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+/* y = x * keep[b] + add   (keep, add nullable) */
+int unetk_scale_sample(const void* x, const float* keep, const void* add, void* y, int B, int64_t per_sample,
+                       int dtype, hipStream_t stream) {
+  UNETK_CHECK_ARG(x && y && B > 0 && per_sample > 0, "scale_sample: bad arguments");
+  CHECK_DT("scale_sample", dtype);
+  UNETK_CHECK_ARG(per_sample % VEC_OF(dtype) == 0, "scale_sample: sample size not a multiple of the vector width");
+  const long vps = per_sample / VEC_OF(dtype);
+  const long nv = vps * B;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(scale_sample_kernel<T>, dim3(cdiv(nv, 256)), dim3(256), 0, stream,
+                                       (const T*)x, keep, (const T*)add, (T*)y, nv, vps));
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_patchify(const float* x, void* tok, int B, int Cin, int H, int W, int ps, int ld, int dtype,
+                   hipStream_t stream) {
+  UNETK_CHECK_ARG(x && tok && ps > 0 && H >= ps && W >= ps && ld >= Cin * ps * ps, "patchify: bad arguments");
+  CHECK_DT("patchify", dtype);
+  const int Hp = H / ps, Wp = W / ps;
+  const long total = (long)B * Hp * Wp * ld;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(patchify_kernel<T>, dim3(cdiv(total, 256)), dim3(256), 0, stream, x, (T*)tok,
+                                       B, Cin, H, W, ps, Hp, Wp, ld));
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_unpatchify(const void* dtok, float* dx, int B, int Cin, int H, int W, int ps, int ld, int dtype,
+                     hipStream_t stream) {
+  UNETK_CHECK_ARG(dtok && dx && ps > 0, "unpatchify: bad arguments");
+  CHECK_DT("unpatchify", dtype);
+  const long total = (long)B * Cin * H * W;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(unpatchify_kernel<T>, dim3(cdiv(total, 256)), dim3(256), 0, stream,
+                                       (const T*)dtok, dx, B, Cin, H, W, ps, H / ps, W / ps, ld));
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_merge_gather(const void* x, void* out, int B, int H, int W, int C, int backward, int dtype,
+                       hipStream_t stream) {
+  UNETK_CHECK_ARG(x && out, "merge_gather: null pointer");
+  CHECK_DT("merge_gather", dtype);
+  UNETK_CHECK_ARG(C % VEC_OF(dtype) == 0, "merge_gather: C=%d not a multiple of %d", C, VEC_OF(dtype));
+  const int E = VEC_OF(dtype);
+  if (!backward) {
+    const long total = (long)B * ((H + 1) / 2) * ((W + 1) / 2) * 4 * (C / E);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(merge_gather_kernel<T>, dim3(cdiv(total, 256)), dim3(256), 0, stream,
+                                         (const T*)x, (T*)out, B, H, W, C));
+  } else {   // x = gradient of the merged tensor, out = gradient of the (B,H,W,C) input
+    const long total = (long)B * H * W * (C / E);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(merge_scatter_kernel<T>, dim3(cdiv(total, 256)), dim3(256), 0, stream,
+                                         (const T*)x, (T*)out, B, H, W, C));
+  }
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_pixel_shuffle(void* tmp, void* cat, int ldcat, const float* bias, int B, int h, int w, int Co,
+                        int backward, int dtype, hipStream_t stream) {
+  UNETK_CHECK_ARG(tmp && cat, "pixel_shuffle: null pointer");
+  CHECK_DT("pixel_shuffle", dtype);
+  const int E = VEC_OF(dtype);
+  UNETK_CHECK_ARG(Co % E == 0 && ldcat % E == 0, "pixel_shuffle: channels not a multiple of %d", E);
+  const long total = (long)B * h * w * 4 * (Co / E);
+  if (backward) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((pixel_shuffle_kernel<T, true>), dim3(cdiv(total, 256)), dim3(256), 0,
+                                         stream, (T*)tmp, (T*)cat, ldcat, bias, B, h, w, Co));
+  } else {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((pixel_shuffle_kernel<T, false>), dim3(cdiv(total, 256)), dim3(256), 0,
+                                         stream, (T*)tmp, (T*)cat, ldcat, bias, B, h, w, Co));
+  }
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+static int check_attn(const char* name, int He, int We, int C, int heads, int shift) {
+  UNETK_CHECK_ARG(heads > 0 && C == heads * HD, "%s: head dimension must be %d (C=%d heads=%d)", name, HD, C, heads);
+  UNETK_CHECK_ARG(He % WS == 0 && We % WS == 0 && He > 0 && We > 0, "%s: token grid %dx%d not a multiple of %d", name,
+                  He, We, WS);
+  UNETK_CHECK_ARG(shift >= 0 && shift < WS, "%s: bad shift %d", name, shift);
+  return UNETK_OK;
+}
+
+int unetk_window_attn_fwd(const void* qkv, void* out, const float* table, int B, int He, int We, int C, int heads,
+                          int shift, int use_mask, float scale, int dtype, hipStream_t stream) {
+  UNETK_CHECK_ARG(qkv && out && table && B > 0, "window_attn_fwd: bad arguments");
+  CHECK_DT("window_attn_fwd", dtype);
+  if (int rc = check_attn("window_attn_fwd", He, We, C, heads, shift)) return rc;
+  AttnGeom g{B, He, We, C, heads, shift, use_mask, scale};
+  const int nblk = B * (He / WS) * (We / WS) * heads;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(window_attn_fwd_kernel<T>, dim3(nblk), dim3(64), 0, stream, (const T*)qkv,
+                                       (T*)out, table, g));
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+/* dtable_partials: [B*nW*heads][225] floats */
+int unetk_window_attn_bwd(const void* qkv, const void* dout, void* dqkv, const float* table, float* dtable,
+                          float* dtable_partials, int B, int He, int We, int C, int heads, int shift, int use_mask,
+                          float scale, int dtype, hipStream_t stream) {
+  UNETK_CHECK_ARG(qkv && dout && dqkv && table && dtable && dtable_partials && B > 0,
+                  "window_attn_bwd: bad arguments");
+  CHECK_DT("window_attn_bwd", dtype);
+  if (int rc = check_attn("window_attn_bwd", He, We, C, heads, shift)) return rc;
+  AttnGeom g{B, He, We, C, heads, shift, use_mask, scale};
+  const int nwin = B * (He / WS) * (We / WS);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(window_attn_bwd_kernel<T>, dim3(nwin * heads), dim3(64), 0, stream,
+                                       (const T*)qkv, (const T*)dout, (T*)dqkv, table, dtable_partials, g));
+  UNETK_CHECK_LAUNCH();
+  hipLaunchKernelGGL(dtable_reduce_kernel, dim3(225, heads), dim3(64), 0, stream, dtable_partials, nwin, heads,
+                     dtable);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+}  // extern "C"

@@ -75,21 +75,23 @@ def conv_fwd(x: torch.Tensor, pw: PackedConv, Ci: Optional[int] = None, Co: Opti
              act: int = 0, resid=None, resid_keep=None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """x: (B,H,W,ld) NHWC.  Channel counts default to the packed weight's, rounded up to the
     vector width for the output (padding channels come out as exact zeros)."""
-    B, H, W, ldin = x.shape
+    B, H, W, _ = x.shape
+    ldin = x.stride(2)
     dt = x.dtype
     v = _vec(dt)
-    Ci = Ci if Ci is not None else min(ldin, pad_channels(pw.Ci, dt))
-    Co = Co if Co is not None else pad_channels(pw.Co, dt)
+    Ci = Ci if Ci is not None else min(x.shape[-1], pad_channels(pw.Ci, dt))
+    if Co is None:
+        Co = out.shape[-1] if out is not None else pad_channels(pw.Co, dt)
     if out is None:
         out = torch.empty((B, H, W, Co), dtype=dt, device=x.device)
-    ldout = out.shape[-1]
+    ldout = out.stride(2)          # `out` may be a channel slice of a wider (concat) buffer
     stats = None
     if want_stats:
         nt = _lib.load().unetk_conv_num_tiles(B, H, W, pw.ks)
         stats = torch.empty((nt, 2, Co), dtype=torch.float32, device=x.device)
     call("unetk_conv_fwd", ptr(x), ldin, ptr(pw.data), ptr(out), ldout, B, H, W, Ci, Co, pw.ks, pw.bn,
          dtype_code(dt), ptr(stats), ptr(scale), ptr(shift), act, ptr(resid),
-         resid.shape[-1] if resid is not None else 0, ptr(resid_keep), stream())
+         resid.stride(2) if resid is not None else 0, ptr(resid_keep), stream())
     return out, stats
 
 
@@ -97,7 +99,8 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, Ci: int, Co: int, ks: int,
                dw: Optional[torch.Tensor] = None, accumulate: bool = False,
                workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dw (Co,Ci,k,k) fp32 from NHWC activations x (B,H,W,ldx) and output gradient dy (B,H,W,lddy)."""
-    B, H, W, ldx = x.shape
+    B, H, W, _ = x.shape
+    ldx = x.stride(2)
     dt = x.dtype
     v = _vec(dt)
     Cip, Cop = pad_channels(Ci, dt), pad_channels(Co, dt)
@@ -108,7 +111,7 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, Ci: int, Co: int, ks: int,
     tgt = dw
     if dw is None or padded:
         tgt = torch.empty((Cop, Cip, ks, ks), dtype=torch.float32, device=x.device)
-    call("unetk_conv_wgrad", ptr(x), ldx, ptr(dy), dy.shape[-1], ptr(tgt), B, H, W, Cip, Cop, ks,
+    call("unetk_conv_wgrad", ptr(x), ldx, ptr(dy), dy.stride(2), ptr(tgt), B, H, W, Cip, Cop, ks,
          dtype_code(dt), ptr(workspace), workspace.numel() * workspace.element_size(),
          1 if (accumulate and not padded and dw is not None) else 0, stream())
     if padded:
@@ -239,3 +242,125 @@ def head1x1_bwd(x, w, dout, need_dx=True):
     call("unetk_head1x1_bwd", ptr(x), C, ptr(w), ptr(dout), ptr(dx), ptr(dw), ptr(db), B, H, W, C, Co, 0,
          ptr(partials), dtype_code(x.dtype), stream())
     return dx, dw.view(Co, C, 1, 1), db
+
+
+# ---------------------------------------------------------------------------- Swin-UNet pieces
+def layernorm_fwd(x, gamma, beta, eps=1e-5):
+    """x (..., C) contiguous -> (y, mean, rstd) with per-token statistics in fp32."""
+    C = x.shape[-1]
+    ntok = x.numel() // C
+    y = torch.empty_like(x)
+    mean = torch.empty(ntok, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(ntok, dtype=torch.float32, device=x.device)
+    call("unetk_layernorm_fwd", ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ntok, C, eps,
+         dtype_code(x.dtype), stream())
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, add=None, need_param_grads=True):
+    """Returns (dx [+ add], dgamma, dbeta)."""
+    C = x.shape[-1]
+    ntok = x.numel() // C
+    dev = x.device
+    dx = torch.empty_like(x)
+    nparts = _lib.load().unetk_token_reduce_num_partials(ntok)
+    partials = torch.empty((nparts, 2, C), dtype=torch.float32, device=dev)
+    dg = torch.empty(C, dtype=torch.float32, device=dev) if need_param_grads else None
+    db = torch.empty(C, dtype=torch.float32, device=dev) if need_param_grads else None
+    call("unetk_layernorm_bwd", ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(add), ptr(dx), ptr(dg),
+         ptr(db), ptr(partials), ntok, C, dtype_code(x.dtype), stream())
+    return dx, dg, db
+
+
+def channel_sum(x, C=None):
+    """Sum over all tokens of a (..., ld) tensor, first C channels -> (C,) fp32."""
+    ld = x.stride(-2) if x.dim() > 1 else x.shape[-1]
+    C = C if C is not None else x.shape[-1]
+    ntok = x.numel() // x.shape[-1]
+    nparts = _lib.load().unetk_token_reduce_num_partials(ntok)
+    partials = torch.empty((nparts, 2, C), dtype=torch.float32, device=x.device)
+    out = torch.empty(C, dtype=torch.float32, device=x.device)
+    call("unetk_channel_sum", ptr(x), ld, ntok, C, ptr(out), ptr(partials), dtype_code(x.dtype), stream())
+    return out
+
+
+def gelu_fwd(x):
+    y = torch.empty_like(x)
+    call("unetk_gelu_fwd", ptr(x), ptr(y), x.numel(), dtype_code(x.dtype), stream())
+    return y
+
+
+def gelu_bwd(dy, x):
+    dx = torch.empty_like(x)
+    call("unetk_gelu_bwd", ptr(dy), ptr(x), ptr(dx), x.numel(), dtype_code(x.dtype), stream())
+    return dx
+
+
+def scale_sample(x, keep=None, add=None):
+    """x * keep[b] + add for a (B, ...) tensor."""
+    y = torch.empty_like(x)
+    B = x.shape[0]
+    call("unetk_scale_sample", ptr(x), ptr(keep), ptr(add), ptr(y), B, x.numel() // B, dtype_code(x.dtype),
+         stream())
+    return y
+
+
+def patchify(x, ps, dt):
+    x = x.contiguous().float()
+    B, Cin, H, W = x.shape
+    ld = pad_channels(Cin * ps * ps, dt)
+    tok = torch.empty((B, H // ps, W // ps, ld), dtype=dt, device=x.device)
+    call("unetk_patchify", ptr(x), ptr(tok), B, Cin, H, W, ps, ld, dtype_code(dt), stream())
+    return tok
+
+
+def unpatchify(dtok, Cin, H, W, ps):
+    B = dtok.shape[0]
+    dx = torch.empty((B, Cin, H, W), dtype=torch.float32, device=dtok.device)
+    call("unetk_unpatchify", ptr(dtok), ptr(dx), B, Cin, H, W, ps, dtok.shape[-1], dtype_code(dtok.dtype),
+         stream())
+    return dx
+
+
+def merge_gather(x):
+    B, H, W, C = x.shape
+    out = torch.empty((B, (H + 1) // 2, (W + 1) // 2, 4 * C), dtype=x.dtype, device=x.device)
+    call("unetk_merge_gather", ptr(x), ptr(out), B, H, W, C, 0, dtype_code(x.dtype), stream())
+    return out
+
+
+def merge_scatter(dout, H, W):
+    B, _, _, C4 = dout.shape
+    dx = torch.empty((B, H, W, C4 // 4), dtype=dout.dtype, device=dout.device)
+    call("unetk_merge_gather", ptr(dout), ptr(dx), B, H, W, C4 // 4, 1, dtype_code(dout.dtype), stream())
+    return dx
+
+
+def pixel_shuffle(tmp, cat, bias, Co, backward=False):
+    """tmp (B,h,w,4*Co) <-> channels [0,Co) of cat (B,2h,2w,ld)."""
+    B, h, w, _ = tmp.shape
+    call("unetk_pixel_shuffle", ptr(tmp), ptr(cat), cat.stride(2), ptr(bias), B, h, w, Co, 1 if backward else 0,
+         dtype_code(tmp.dtype), stream())
+
+
+def window_attn_fwd(qkv, table, heads, shift, use_mask):
+    B, He, We, C3 = qkv.shape
+    C = C3 // 3
+    out = torch.empty((B, He, We, C), dtype=qkv.dtype, device=qkv.device)
+    call("unetk_window_attn_fwd", ptr(qkv), ptr(out), ptr(table), B, He, We, C, heads, shift,
+         1 if use_mask else 0, (C // heads) ** -0.5, dtype_code(qkv.dtype), stream())
+    return out
+
+
+def window_attn_bwd(qkv, dout, table, heads, shift, use_mask):
+    """Returns (dqkv, dtable (225, heads))."""
+    B, He, We, C3 = qkv.shape
+    C = C3 // 3
+    dev = qkv.device
+    dqkv = torch.empty_like(qkv)
+    nblk = B * (He // 8) * (We // 8) * heads
+    partials = torch.empty((nblk, 225), dtype=torch.float32, device=dev)
+    dtable = torch.empty((225, heads), dtype=torch.float32, device=dev)
+    call("unetk_window_attn_bwd", ptr(qkv), ptr(dout), ptr(dqkv), ptr(table), ptr(dtable), ptr(partials), B, He,
+         We, C, heads, shift, 1 if use_mask else 0, (C // heads) ** -0.5, dtype_code(qkv.dtype), stream())
+    return dqkv, dtable

@@ -1,0 +1,466 @@
+"""SwinUNet on hand-written gfx950 kernels.
+
+Drop-in for the reference class (swin_unet_model.py:139-686): ``SwinUNet(config_dict)`` with the
+same config keys, the same 249 ``state_dict`` entries in the same order, the same initialisation and
+``forward(x: f32[B,in_chans,H,W]) -> f32[B,1,H/2,W/2]`` with autograd.  Tokens live as
+(B,H,W,C) channel-innermost tensors in the compute dtype; every linear layer is the MFMA implicit-GEMM
+kernel run as a 1x1 convolution (bias / residual / DropPath scale in its epilogue), window attention
+is one fused kernel per direction, and the CNN decoder reuses the conv + BatchNorm + ReLU kernels of
+the UNet.  Window size 8 and head dimension 32 (every stage of the reference configuration) are what
+the attention kernel implements; other values raise ValueError.
+"""
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+_WS = 8
+
+
+# ------------------------------------------------------------------ parameter containers
+class DropPath(nn.Module):
+    def __init__(self, drop_prob=None):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+
+class WindowAttention(nn.Module):
+    def __init__(self, dim, window_size, num_heads, qkv_bias=True, attn_drop=0., proj_drop=0.):
+        super().__init__()
+        self.dim, self.num_heads = dim, num_heads
+        self.window_size_tuple = (window_size, window_size) if isinstance(window_size, int) else window_size
+        ws = self.window_size_tuple[0]
+        self.scale = (dim // num_heads) ** -0.5
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * ws - 1) * (2 * ws - 1), num_heads))
+        r = torch.arange(ws)
+        cy, cx = torch.meshgrid(r, r, indexing="ij")
+        cy, cx = cy.reshape(-1), cx.reshape(-1)
+        idx = (cy[:, None] - cy[None, :] + ws - 1) * (2 * ws - 1) + (cx[:, None] - cx[None, :] + ws - 1)
+        self.register_buffer("relative_position_index", idx)
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        nn.init.trunc_normal_(self.relative_position_bias_table, std=.02)
+
+
+class SwinTransformerBlock(nn.Module):
+    def __init__(self, dim, num_heads, window_size=7, shift_size=0, mlp_ratio=4., qkv_bias=True, drop=0.,
+                 attn_drop=0., drop_path=0.):
+        super().__init__()
+        self.dim, self.num_heads, self.window_size, self.shift_size = dim, num_heads, window_size, shift_size
+        self.mlp_ratio = mlp_ratio
+        self.H = self.W = None
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn = WindowAttention(dim, window_size, num_heads, qkv_bias, attn_drop, drop)
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
+        self.norm2 = nn.LayerNorm(dim)
+        hid = int(dim * mlp_ratio)
+        self.mlp = nn.Sequential(nn.Linear(dim, hid), nn.GELU(), nn.Dropout(drop), nn.Linear(hid, dim),
+                                 nn.Dropout(drop))
+
+
+class PatchMerging(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.dim = dim
+        self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
+        self.norm = nn.LayerNorm(4 * dim)
+
+
+class BasicLayer(nn.Module):
+    def __init__(self, dim, depth, num_heads, window_size, mlp_ratio=4., qkv_bias=True, drop=0., attn_drop=0.,
+                 drop_path=0., downsample=None):
+        super().__init__()
+        self.dim, self.depth, self.window_size = dim, depth, window_size
+        self.shift_size = window_size // 2
+        self.blocks = nn.ModuleList([
+            SwinTransformerBlock(dim, num_heads, window_size, 0 if i % 2 == 0 else self.shift_size, mlp_ratio,
+                                 qkv_bias, drop, attn_drop,
+                                 drop_path[i] if isinstance(drop_path, list) else drop_path)
+            for i in range(depth)])
+        self.downsample = downsample(dim=dim) if downsample is not None else None
+
+
+class DecoderBlock(nn.Module):
+    def __init__(self, in_channels, skip_channels, out_channels):
+        super().__init__()
+        up = in_channels // 2
+        self.upsample = nn.ConvTranspose2d(in_channels, up, kernel_size=2, stride=2)
+        cin = up
+        if skip_channels is not None and skip_channels > 0:
+            self.skip_projection = nn.Conv2d(skip_channels, up, kernel_size=1, bias=False)
+            cin += up
+        else:
+            self.skip_projection = None
+        self.conv_block = nn.Sequential(
+            nn.Conv2d(cin, out_channels, kernel_size=3, padding=1, bias=False), nn.BatchNorm2d(out_channels),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(out_channels, out_channels, kernel_size=3, padding=1, bias=False),
+            nn.BatchNorm2d(out_channels), nn.ReLU(inplace=True))
+
+
+class SwinUNet(nn.Module):
+    def __init__(self, config_dict, compute_dtype=torch.float32):
+        super().__init__()
+        c = config_dict
+        self.patch_size_val, self.in_chans, self.embed_dim_val = c["patch_size"], c["in_chans"], c["embed_dim"]
+        self.depths, self.num_heads, self.window_size = c["depths"], c["num_heads"], c["window_size"]
+        self.mlp_ratio, self.drop_rate = c["mlp_ratio"], c["drop_rate"]
+        self.attn_drop_rate, self.drop_path_rate = c["attn_drop_rate"], c["drop_path_rate"]
+        self.num_layers = len(self.depths)
+        self.patch_norm = True
+        self.compute_dtype = compute_dtype
+        if self.window_size != _WS:
+            raise ValueError(f"the window-attention kernel implements window_size {_WS}, got {self.window_size}")
+        if self.drop_rate != 0.0 or self.attn_drop_rate != 0.0:
+            raise ValueError("element dropout inside attention / MLP (drop_rate, attn_drop_rate) is not "
+                             "implemented; the reference configuration uses 0.0")
+        self.patch_embed = nn.Conv2d(self.in_chans, self.embed_dim_val, kernel_size=self.patch_size_val,
+                                     stride=self.patch_size_val)
+        self.norm_embed = nn.LayerNorm(self.embed_dim_val)
+        self.pos_drop = nn.Dropout(p=self.drop_rate)
+        dpr = [x.item() for x in torch.linspace(0, self.drop_path_rate, sum(self.depths))]
+        self.layers = nn.ModuleList()
+        dim = self.embed_dim_val
+        for i in range(self.num_layers):
+            if dim // self.num_heads[i] != 32 or dim % self.num_heads[i]:
+                raise ValueError("the window-attention kernel implements head dimension 32")
+            self.layers.append(BasicLayer(
+                dim, self.depths[i], self.num_heads[i], self.window_size, self.mlp_ratio, True, self.drop_rate,
+                self.attn_drop_rate, dpr[sum(self.depths[:i]):sum(self.depths[:i + 1])],
+                PatchMerging if i < self.num_layers - 1 else None))
+            if i < self.num_layers - 1:
+                dim = int(dim * 2)
+        self.decoder_channels_conf = c["decoder_channels"]
+        self.decoders = nn.ModuleList()
+        cin = dim
+        for i, co in enumerate(self.decoder_channels_conf):
+            si = self.num_layers - 2 - i
+            self.decoders.append(DecoderBlock(cin, int(self.embed_dim_val * 2 ** si) if si >= 0 else None, co))
+            cin = co
+        self.final_conv = nn.Sequential(nn.Conv2d(cin, 32, kernel_size=3, padding=1), nn.BatchNorm2d(32),
+                                        nn.ReLU(inplace=True), nn.Conv2d(32, 1, kernel_size=1))
+        self.apply(self._init_weights)
+        # test hook: per block [keep1, keep2] (B,) DropPath scales (or None) used instead of fresh draws
+        self.drop_path_override: Optional[List] = None
+
+    def _init_weights(self, m):
+        # reference swin_unet_model.py:616-630 (ConvTranspose2d is not a Conv2d: keeps its default init)
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+        elif isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+
+    def _draw_drop_path(self, B, device):
+        if self.drop_path_override is not None:
+            return [[None if k is None else k.to(device=device, dtype=torch.float32).contiguous() for k in pair]
+                    for pair in self.drop_path_override]
+        out = []
+        for layer in self.layers:
+            for blk in layer.blocks:
+                p = blk.drop_path.drop_prob if isinstance(blk.drop_path, DropPath) else 0.0
+                if not p:
+                    out.append([None, None])
+                else:   # floor(keep_prob + U[0,1)) / keep_prob per sample (:139-148), once per branch
+                    out.append([(torch.rand(B, device=device) + (1 - p)).floor_() / (1 - p) for _ in range(2)])
+        return out
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("unet_amd.SwinUNet runs on the GPU only (hand-written gfx950 kernels, no CPU "
+                               "fallback); move the module and its input to 'cuda'")
+        if x.dim() != 4 or x.shape[1] != self.in_chans:
+            raise RuntimeError(f"expected input (B,{self.in_chans},H,W), got {tuple(x.shape)}")
+        ps = self.patch_size_val
+        Hp, Wp = x.shape[2] // ps, x.shape[3] // ps
+        for _ in range(self.num_layers - 1):
+            Hp, Wp = (Hp + 1) // 2, (Wp + 1) // 2
+        if Hp == 0 or Wp == 0:     # reference fallback (:664-668)
+            return torch.zeros((x.shape[0], 1, x.shape[2], x.shape[3]), device=x.device, dtype=x.dtype)
+        if self.training:
+            dp = self._draw_drop_path(x.shape[0], x.device)
+            return _SwinTrainFn.apply(x, self, dp, *list(self.parameters()))
+        with torch.no_grad():
+            return _forward(self, x, None, None)
+
+
+# ------------------------------------------------------------------ building blocks
+def _linear(x, w, b, dt, act=0, resid=None, keep=None, out=None):
+    return ops.conv_fwd(x, ops.PackedConv(w, dt), scale=None, shift=b, act=act, resid=resid, resid_keep=keep,
+                        out=out)[0]
+
+
+def _linear_bwd(x, dy, w, dt, grads, wname, bname, need_dx=True):
+    Co, Ci = w.shape[0], w.shape[1]
+    grads[wname] = ops.conv_wgrad(x, dy, Ci, Co, 1).view(w.shape)
+    if bname is not None:
+        grads[bname] = ops.channel_sum(dy, Co)
+    if need_dx:
+        return ops.conv_fwd(dy, ops.PackedConv(w.view(Co, Ci), dt, transpose=True))[0]
+    return None
+
+
+def _check_grid(H, W):
+    for n in (H, W):
+        if n > _WS and n % _WS:
+            raise RuntimeError(f"shape is invalid for window partition: a {H}x{W} token grid is not a multiple "
+                               f"of the window size {_WS}")
+
+
+def _pad_tokens(t, He, We):
+    B, H, W, C = t.shape
+    if (He, We) == (H, W):
+        return t
+    p = torch.zeros((B, He, We, C), dtype=t.dtype, device=t.device)
+    p[:, :H, :W] = t
+    return p
+
+
+def _block_fwd(blk, pre, x, keep1, keep2, dt, save):
+    """One SwinTransformerBlock (:305-374) on tokens x (B,H,W,C)."""
+    B, H, W, C = x.shape
+    _check_grid(H, W)
+    He, We = max(H, _WS), max(W, _WS)
+    padded = (He, We) != (H, W)
+    a = blk.attn
+    ln1, m1, r1 = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
+    ln1p = _pad_tokens(ln1, He, We)
+    qkv = _linear(ln1p, a.qkv.weight, a.qkv.bias, dt)
+    # the shift mask is built for every stage and handed to every block, shifted or not (:458-484)
+    att = ops.window_attn_fwd(qkv, a.relative_position_bias_table, a.num_heads, blk.shift_size, True)
+    if not padded:
+        x1 = _linear(att, a.proj.weight, a.proj.bias, dt, resid=x, keep=keep1)
+    else:
+        pr = _linear(att, a.proj.weight, a.proj.bias, dt)
+        x1 = ops.scale_sample(pr[:, :H, :W].contiguous(), keep1, x)
+    ln2, m2, r2 = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+    hpre = _linear(ln2, blk.mlp[0].weight, blk.mlp[0].bias, dt)
+    hact = ops.gelu_fwd(hpre)
+    x2 = _linear(hact, blk.mlp[3].weight, blk.mlp[3].bias, dt, resid=x1, keep=keep2)
+    if save is not None:
+        save.append(("block", blk, pre, (x, m1, r1, ln1p, qkv, att, x1, m2, r2, ln2, hpre, hact, keep1, keep2,
+                                          (H, W, He, We))))
+    return x2
+
+
+def _block_bwd(blk, pre, ctx, dx2, dt, grads):
+    x, m1, r1, ln1p, qkv, att, x1, m2, r2, ln2, hpre, hact, keep1, keep2, (H, W, He, We) = ctx
+    a = blk.attn
+    padded = (He, We) != (H, W)
+    # MLP branch
+    db = ops.scale_sample(dx2, keep2) if keep2 is not None else dx2
+    dh = _linear_bwd(hact, db, blk.mlp[3].weight, dt, grads, pre + "mlp.3.weight", pre + "mlp.3.bias")
+    dhp = ops.gelu_bwd(dh, hpre)
+    dln2 = _linear_bwd(ln2, dhp, blk.mlp[0].weight, dt, grads, pre + "mlp.0.weight", pre + "mlp.0.bias")
+    dx1, grads[pre + "norm2.weight"], grads[pre + "norm2.bias"] = ops.layernorm_bwd(
+        dln2, x1, blk.norm2.weight, m2, r2, add=dx2)
+    # attention branch
+    db = ops.scale_sample(dx1, keep1) if keep1 is not None else dx1
+    dbp = _pad_tokens(db, He, We) if padded else db
+    datt = _linear_bwd(att, dbp, a.proj.weight, dt, grads, pre + "attn.proj.weight", pre + "attn.proj.bias")
+    dqkv, grads[pre + "attn.relative_position_bias_table"] = ops.window_attn_bwd(
+        qkv, datt, a.relative_position_bias_table, a.num_heads, blk.shift_size, True)
+    dln1 = _linear_bwd(ln1p, dqkv, a.qkv.weight, dt, grads, pre + "attn.qkv.weight", pre + "attn.qkv.bias")
+    if padded:
+        dln1 = dln1[:, :H, :W].contiguous()
+    dx, grads[pre + "norm1.weight"], grads[pre + "norm1.bias"] = ops.layernorm_bwd(
+        dln1, x, blk.norm1.weight, m1, r1, add=dx1)
+    return dx
+
+
+def _conv_bn_relu_fwd(conv, bn, t, dt, training, save, tag):
+    """Conv3x3 -> BatchNorm2d -> ReLU.  A conv bias in front of BatchNorm only moves running_mean."""
+    pk = ops.PackedConv(conv.weight, dt)
+    if not training:
+        sc, sh = ops.bn_fold_eval(bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.bias, bn.eps)
+        return ops.conv_fwd(t, pk, scale=sc, shift=sh, act=1)[0]
+    y, stats = ops.conv_fwd(t, pk, want_stats=True)
+    Bn, H, W, _ = y.shape
+    mean, invstd, sc, sh = ops.bn_finalize(stats, Bn * H * W, bn.weight, bn.bias, bn.running_mean,
+                                           bn.running_var, bn.eps, bn.momentum if bn.momentum is not None else 0.1)
+    if conv.bias is not None:
+        bn.running_mean.add_(conv.bias.detach(), alpha=bn.momentum if bn.momentum is not None else 0.1)
+    bn.num_batches_tracked += 1
+    a, _ = ops.bn_act_fwd(y, sc, sh, None, relu=True)
+    if save is not None:
+        save.append(("cbr", conv, bn, tag, (t, y, mean, invstd, sc, sh)))
+    return a
+
+
+def _conv_bn_relu_bwd(conv, bn, tag, ctx, g, dt, grads, need_dx=True):
+    t, y, mean, invstd, sc, sh = ctx
+    dy, dgamma, dbeta = ops.bn_act_bwd(g, y, sc, sh, mean, invstd, None, relu=True)
+    cname, bname = tag
+    grads[bname + ".weight"], grads[bname + ".bias"] = dgamma, dbeta
+    grads[cname + ".weight"] = ops.conv_wgrad(t, dy, conv.in_channels, conv.out_channels, 3)
+    if conv.bias is not None:
+        grads[cname + ".bias"] = torch.zeros_like(conv.bias)      # exactly 0 in front of BatchNorm
+    if need_dx:
+        return ops.conv_fwd(dy, ops.PackedConv(conv.weight, dt, transpose=True))[0]
+    return None
+
+
+def _decoder_fwd(dec, pre, x, skip, dt, training, save):
+    """DecoderBlock (:520-535): ConvTranspose(2,2)+bias, 1x1 skip projection, concat, DoubleConv."""
+    B, h, w, Cin = x.shape
+    up = dec.upsample.out_channels
+    has_skip = skip is not None and dec.skip_projection is not None
+    cat = torch.empty((B, 2 * h, 2 * w, up * (2 if has_skip else 1)), dtype=dt, device=x.device)
+    w2 = dec.upsample.weight.permute(2, 3, 1, 0).reshape(4 * up, Cin)       # [(ky,kx,co)][ci]
+    tmp = _linear(x, w2, None, dt)
+    ops.pixel_shuffle(tmp, cat, dec.upsample.bias, up)
+    resized = None
+    if has_skip:
+        if skip.shape[1:3] == (2 * h, 2 * w):
+            ops.conv_fwd(skip, ops.PackedConv(dec.skip_projection.weight, dt), out=cat[..., up:])
+        else:       # bilinear resize of the projected skip to the upsampled size (:526-529)
+            sp = _linear(skip, dec.skip_projection.weight.view(up, -1), None, dt)
+            resized = sp.shape[1:3]
+            cat[..., up:] = ops.upsample_concat(sp, torch.empty((B, 2 * h, 2 * w, 0), dtype=dt, device=x.device))
+    if save is not None:
+        save.append(("dec_head", dec, pre, (x, skip, w2, resized)))
+    t = _conv_bn_relu_fwd(dec.conv_block[0], dec.conv_block[1], cat, dt, training, save,
+                          (pre + "conv_block.0", pre + "conv_block.1"))
+    return _conv_bn_relu_fwd(dec.conv_block[3], dec.conv_block[4], t, dt, training, save,
+                             (pre + "conv_block.3", pre + "conv_block.4"))
+
+
+def _decoder_head_bwd(dec, pre, ctx, dcat, dt, grads):
+    """Returns (dx, dskip or None)."""
+    x, skip, w2, resized = ctx
+    B, h, w, Cin = x.shape
+    up = dec.upsample.out_channels
+    dtmp = torch.empty((B, h, w, 4 * up), dtype=dt, device=x.device)
+    ops.pixel_shuffle(dtmp, dcat, None, up, backward=True)
+    grads[pre + "upsample.bias"] = ops.channel_sum(dcat, up)
+    dw2 = ops.conv_wgrad(x, dtmp, Cin, 4 * up, 1).view(2, 2, up, Cin)
+    grads[pre + "upsample.weight"] = dw2.permute(3, 2, 0, 1).contiguous()
+    dx = ops.conv_fwd(dtmp, ops.PackedConv(w2.contiguous(), dt, transpose=True))[0]
+    dskip = None
+    if skip is not None and dec.skip_projection is not None:
+        wsk = dec.skip_projection.weight
+        dsp = dcat[..., up:]
+        if resized is not None:
+            dsp = ops.upsample_bwd(dsp.contiguous(), up, resized[0], resized[1])
+        grads[pre + "skip_projection.weight"] = ops.conv_wgrad(skip, dsp, wsk.shape[1], up, 1).view(wsk.shape)
+        dskip = ops.conv_fwd(dsp, ops.PackedConv(wsk, dt, transpose=True))[0]
+    return dx, dskip
+
+
+def _forward(model, x, drop_path, save):
+    """Whole network.  save=None: inference (BatchNorm folded, nothing kept)."""
+    dt = model.compute_dtype
+    training = save is not None
+    ps = model.patch_size_val
+    E = model.embed_dim_val
+    tok_in = ops.patchify(x.detach(), ps, dt)
+    wpe = model.patch_embed.weight.reshape(E, -1)
+    t0 = _linear(tok_in, wpe, model.patch_embed.bias, dt)
+    t, m0, r0 = ops.layernorm_fwd(t0, model.norm_embed.weight, model.norm_embed.bias, model.norm_embed.eps)
+    if training:
+        save.append(("embed", (tok_in, t0, m0, r0)))
+    skips = []
+    bno = 0
+    for li, layer in enumerate(model.layers):
+        for bi, blk in enumerate(layer.blocks):
+            k1, k2 = drop_path[bno] if (training and drop_path is not None) else (None, None)
+            t = _block_fwd(blk, f"layers.{li}.blocks.{bi}.", t, k1, k2, dt, save)
+            bno += 1
+        skips.append(t)
+        if layer.downsample is not None:
+            ds = layer.downsample
+            mg = ops.merge_gather(t)
+            ln, mm, rr = ops.layernorm_fwd(mg, ds.norm.weight, ds.norm.bias, ds.norm.eps)
+            nxt = _linear(ln, ds.reduction.weight, None, dt)
+            if training:
+                save.append(("merge", ds, f"layers.{li}.downsample.", li, (t.shape, mg, mm, rr, ln)))
+            t = nxt
+    d = t
+    nl = model.num_layers
+    for i, dec in enumerate(model.decoders):
+        si = nl - 2 - i
+        d = _decoder_fwd(dec, f"decoders.{i}.", d, skips[si] if si >= 0 else None, dt, training, save)
+        if training:
+            save.append(("dec_tail", i, si))
+    fc = model.final_conv
+    f = _conv_bn_relu_fwd(fc[0], fc[1], d, dt, training, save, ("final_conv.0", "final_conv.1"))
+    out = ops.head1x1_fwd(f, fc[3].weight, fc[3].bias)
+    if training:
+        save.append(("head", f))
+    return out
+
+
+class _SwinTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, model, drop_path, *params):
+        save: List = []
+        out = _forward(model, x, drop_path, save)
+        ctx.model, ctx.save, ctx.in_shape = model, save, x.shape
+        ctx.need_dx = ctx.needs_input_grad[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        model, save = ctx.model, ctx.save
+        dt = model.compute_dtype
+        grads: Dict[str, torch.Tensor] = {}
+        nl = model.num_layers
+        dskips: Dict[int, torch.Tensor] = {}
+        g = None
+        pending_skip = None
+        for rec in reversed(save):
+            kind = rec[0]
+            if kind == "head":
+                fc = model.final_conv
+                g, dw, db = ops.head1x1_bwd(rec[1], fc[3].weight, dout)
+                grads["final_conv.3.weight"], grads["final_conv.3.bias"] = dw, db
+            elif kind == "cbr":
+                _, conv, bn, tag, c = rec
+                g = _conv_bn_relu_bwd(conv, bn, tag, c, g, dt, grads)
+            elif kind == "dec_tail":
+                pass
+            elif kind == "dec_head":
+                _, dec, pre, c = rec
+                i = int(pre.split(".")[1])
+                g, dsk = _decoder_head_bwd(dec, pre, c, g, dt, grads)
+                if dsk is not None:
+                    dskips[nl - 2 - i] = dsk
+            elif kind == "merge":
+                _, ds, pre, li, (shape, mg, mm, rr, ln) = rec
+                dln = _linear_bwd(ln, g, ds.reduction.weight, dt, grads, pre + "reduction.weight", None)
+                dmg, grads[pre + "norm.weight"], grads[pre + "norm.bias"] = ops.layernorm_bwd(
+                    dln, mg, ds.norm.weight, mm, rr)
+                g = ops.merge_scatter(dmg, shape[1], shape[2])
+                if li in dskips:       # the stage output also feeds a decoder skip
+                    g = ops.scale_sample(g, None, dskips.pop(li))
+            elif kind == "block":
+                _, blk, pre, c = rec
+                g = _block_bwd(blk, pre, c, g, dt, grads)
+            elif kind == "embed":
+                tok_in, t0, m0, r0 = rec[1]
+                E = model.embed_dim_val
+                dt0, grads["norm_embed.weight"], grads["norm_embed.bias"] = ops.layernorm_bwd(
+                    g, t0, model.norm_embed.weight, m0, r0)
+                wpe = model.patch_embed.weight.reshape(E, -1)
+                K = wpe.shape[1]
+                grads["patch_embed.weight"] = ops.conv_wgrad(tok_in, dt0, K, E, 1).view(model.patch_embed.weight.shape)
+                grads["patch_embed.bias"] = ops.channel_sum(dt0, E)
+                g = None
+                if ctx.need_dx:
+                    dtok = ops.conv_fwd(dt0, ops.PackedConv(wpe, dt, transpose=True))[0]
+                    B, Cin, H, W = ctx.in_shape
+                    g = ops.unpatchify(dtok, Cin, H, W, model.patch_size_val)
+        ctx.save = None
+        outg = [grads.get(n) if p.requires_grad else None for n, p in model.named_parameters()]
+        return (g if ctx.need_dx else None, None, None, *outg)
