@@ -1,2 +1,5 @@
 """unet_amd: MI355X-native kernels behind the reference's UNet / Swin-UNet / loss / tiled-predict API."""
 from .unet import OptimizedUNet  # noqa: F401
+from .losses import MultiLossFunction, TIDWeightedLoss, GradientLoss, SpectralLoss  # noqa: F401
+from .swin import SwinUNet  # noqa: F401
+from .predictor import LargeAreaPredictor, LargeAreaPredictionConfig  # noqa: F401
