@@ -22,7 +22,18 @@
 #include "common.h"
 #include "mma.h"
 
+// what out-of-image pixels and channel padding load
+__device__ __attribute__((aligned(64))) unsigned int unetk_zero_page[16];
+
 namespace {
+
+// LDS-DMA: 16 bytes per lane from `src` to (wave-uniform) `lds_dst` + lane*16.  The builtin exists
+// only in the device pass; the host pass just needs the kernel's signature.
+__device__ __forceinline__ void glds16(const void* src, char* lds_dst) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_global_load_lds(src, LDS_PTR(void, lds_dst), 16, 0, 0);
+#endif
+}
 
 struct ConvArgs {
   const void* in;
@@ -40,7 +51,9 @@ struct ConvArgs {
   int tiles_x, tiles_y;
 };
 
-constexpr int ROWB = 80;   // LDS bytes per staged row: 64 data + 16 pad
+constexpr int ROWB = 64;   // LDS bytes per staged row (unpadded, slots swizzled: see swz())
+
+
 
 __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
@@ -56,17 +69,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   constexpr int HPIX = HALO * HALO;
   constexpr int TAPS = KS * KS;
   constexpr int WROWS = KS * BN;
-  constexpr int MAIN_BYTES = (HPIX + WROWS) * ROWB;
+  // Operand staging is LDS-DMA (global_load_lds, 16 B per lane, 1 KiB per wave instruction) into
+  // double buffers: while phase p (one kernel row of one channel chunk) is being multiplied, the
+  // weights of phase p+1 (and, at a chunk boundary, the next halo) are already in flight.  One
+  // barrier per phase.  The LDS image is lane-linear, so the slot swizzle is applied to the SOURCE
+  // address of each lane; out-of-image pixels and channel padding read a page of zeros.
+  constexpr int HINSTR = (HPIX * 4 + 63) / 64;          // wave instructions per halo
+  constexpr int WINSTR = (WROWS * 4) / 64;              // per weight slab (BN multiple of 16: exact)
+  static_assert((WROWS * 4) % 64 == 0, "weight slab must be whole wave instructions");
+  constexpr int HBUF = HINSTR * 1024, WBUF = WINSTR * 1024;
+  constexpr int MAIN_BYTES = 2 * HBUF + 2 * WBUF;
   constexpr int STAGE_BYTES = 4 * 16 * BN * (int)sizeof(T);
-  constexpr int LDS_BYTES = MAIN_BYTES > STAGE_BYTES ? MAIN_BYTES : STAGE_BYTES;
-  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
-  __shared__ float red[4][2][BN];
-  char* lds_halo = lds;
-  char* lds_w = lds + HPIX * ROWB;
+  constexpr int RED_BYTES = 4 * 2 * BN * (int)sizeof(float);
+  constexpr int LDS_BYTES = MAIN_BYTES > STAGE_BYTES + RED_BYTES ? MAIN_BYTES : STAGE_BYTES + RED_BYTES;
+  __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
+  // per-wave statistics scratch aliases the operand area (behind the epilogue staging tiles)
+  float (*red)[2][BN] = reinterpret_cast<float (*)[2][BN]>(lds + STAGE_BYTES);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nb = blockIdx.y;
   const int n0 = nb * BN;
   const T* in = reinterpret_cast<const T*>(a.in);
@@ -95,54 +117,72 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int ch = 0; ch < a.nchunks; ++ch) {
+  const T* zero = reinterpret_cast<const T*>(unetk_zero_page);
+  auto issue_halo = [&](int ch) {
+    char* dst = lds + (ch & 1) * HBUF;
     const int c0 = ch * KC;
-    __syncthreads();   // every wave is done reading the previous chunk
-    // ---- stage the input halo of this chunk
-    for (int idx = tid; idx < HPIX * 4; idx += 256) {
-      const int pix = idx >> 2, part = idx & 3;
-      const int c = c0 + part * EPP;
-      Vec16<T> v = zero16<T>();
+    for (int i = wave; i < HINSTR; i += 4) {
+      const int part = i * 64 + lane;
+      const int pix = part >> 2;
+      const int c = c0 + ((part & 3) ^ swz(pix)) * EPP;
+      const T* src = zero;
       if (KS == 3) {
         const int hy = pix / HALO, hx = pix - hy * HALO;
         const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.Ci)
-          v = load16(in + (((long)b * a.H + gy) * a.W + gx) * a.ldin + c);
+        if (pix < HPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.Ci)
+          src = in + (((long)b * a.H + gy) * a.W + gx) * a.ldin + c;
       } else {
         const long p = p0 + pix;
-        if (p < npix && c < a.Ci) v = load16(in + p * a.ldin + c);
+        if (p < npix && c < a.Ci) src = in + p * a.ldin + c;
       }
-      store16(reinterpret_cast<T*>(lds_halo + pix * ROWB + part * 16), v);
+      glds16(src, dst + i * 1024);
     }
+  };
+  auto issue_w = [&](int phase) {
+    const int ch = phase / KS, ky = phase - ch * KS;
+    char* dst = lds + 2 * HBUF + (phase & 1) * WBUF;
+    const T* wsrc = wp + ((((long)nb * a.nchunks + ch) * TAPS + ky * KS) * BN) * KC;
+    for (int i = wave; i < WINSTR; i += 4) {
+      const int part = i * 64 + lane;
+      const int row = part >> 2;
+      glds16(wsrc + row * KC + ((part & 3) ^ swz(row)) * EPP, dst + i * 1024);
+    }
+  };
+
+  const int nphase = a.nchunks * KS;
+  issue_halo(0);
+  issue_w(0);
 #pragma unroll 1
-    for (int ky = 0; ky < KS; ++ky) {
-      if (ky > 0) __syncthreads();   // previous kernel row's weights no longer read
-      const T* wsrc = wp + ((((long)nb * a.nchunks + ch) * TAPS + ky * KS) * BN) * KC;
-      for (int idx = tid; idx < WROWS * 4; idx += 256) {
-        const int row = idx >> 2, part = idx & 3;
-        store16(reinterpret_cast<T*>(lds_w + row * ROWB + part * 16),
-                load16(wsrc + row * KC + part * EPP));
-      }
-      __syncthreads();
+  for (int phase = 0; phase < nphase; ++phase) {
+    const int ch = phase / KS, ky = phase - ch * KS;
+    // the DMA of this phase has landed for every wave, and everyone is done with phase-1's buffers
+    __syncthreads();
+    if (phase + 1 < nphase) {
+      issue_w(phase + 1);
+      if (ky == KS - 1) issue_halo(ch + 1);
+    }
+    const char* lds_halo = lds + (ch & 1) * HBUF;
+    const char* lds_w = lds + 2 * HBUF + (phase & 1) * WBUF;
 #pragma unroll
-      for (int kx = 0; kx < KS; ++kx) {
+    for (int kx = 0; kx < KS; ++kx) {
 #pragma unroll
-        for (int ks = 0; ks < M::KSTEPS; ++ks) {
-          typename M::frag af[4], bfr[NT];
+      for (int ks = 0; ks < M::KSTEPS; ++ks) {
+        typename M::frag af[4], bfr[NT];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int prow = (KS == 3) ? ((4 * wave + i + ky) * HALO + kx + (lane & 15))
-                                       : ((4 * wave + i) * 16 + (lane & 15));
-            af[i] = M::load(lds_halo + prow * ROWB, ks, lane);
-          }
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-            bfr[j] = M::load(lds_w + (kx * BN + j * 16 + (lane & 15)) * ROWB, ks, lane);
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = M::mma(af[i], bfr[j], acc[i][j]);
+        for (int i = 0; i < 4; ++i) {
+          const int prow = (KS == 3) ? ((4 * wave + i + ky) * HALO + kx + (lane & 15))
+                                     : ((4 * wave + i) * 16 + (lane & 15));
+          af[i] = M::load_swz(lds_halo + prow * ROWB, ks, lane, swz(prow));
         }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int wrow = kx * BN + j * 16 + (lane & 15);
+          bfr[j] = M::load_swz(lds_w + wrow * ROWB, ks, lane, swz(wrow));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = M::mma(af[i], bfr[j], acc[i][j]);
       }
     }
   }
@@ -173,6 +213,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     return (pixbase[i] + 4 * pg + r) < npix;
   };
 
+  __syncthreads();   // every wave is done reading the operand tiles: LDS is reused from here on
   if (a.stats != nullptr) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -196,7 +237,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       }
     }
   }
-  __syncthreads();   // all MFMA reads of lds done; red[] visible
+  __syncthreads();   // red[] visible
   if (a.stats != nullptr && tid < BN && n0 + tid < a.Co) {
     const float s = red[0][0][tid] + red[1][0][tid] + red[2][0][tid] + red[3][0][tid];
     const float q = red[0][1][tid] + red[1][1][tid] + red[2][1][tid] + red[3][1][tid];

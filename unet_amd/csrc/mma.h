@@ -15,6 +15,10 @@ template <> struct MMA<bf16> {
   static __device__ __forceinline__ frag load(const char* row, int ks, int lane) {
     return *reinterpret_cast<const frag*>(row + (lane >> 4) * 16);
   }
+  // sw = swz(row index): the 16-byte slot of a 64-byte row is XORed with it
+  static __device__ __forceinline__ frag load_swz(const char* row, int ks, int lane, int sw) {
+    return *reinterpret_cast<const frag*>(row + (((lane >> 4) ^ sw) * 16));
+  }
   static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
   }
@@ -26,9 +30,17 @@ template <> struct MMA<float> {
   static __device__ __forceinline__ frag load(const char* row, int ks, int lane) {
     return *reinterpret_cast<const float*>(row + (ks * 4 + (lane >> 4)) * 4);
   }
+  static __device__ __forceinline__ frag load_swz(const char* row, int ks, int lane, int sw) {
+    return *reinterpret_cast<const float*>(row + ((ks ^ sw) * 4 + (lane >> 4)) * 4);
+  }
   static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
   }
 };
+
+// Swizzle of unpadded 64-byte LDS rows: slot ^= 2 on every other group of four rows.  With it a
+// ds_read_b128 fragment read of 16 consecutive rows (any starting row) touches 16 distinct 16-byte
+// slots of the 256-byte bank row in each of the instruction's four lane groups: conflict-free.
+__device__ __forceinline__ int swz(int row) { return ((row >> 2) & 1) << 1; }
 
 }  // namespace
