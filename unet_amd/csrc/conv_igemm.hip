@@ -22,10 +22,10 @@
 #include "common.h"
 #include "mma.h"
 
-// what out-of-image pixels and channel padding load
-__device__ __attribute__((aligned(64))) unsigned int unetk_zero_page[16];
-
 namespace {
+
+// what out-of-image pixels and channel padding load
+__device__ __attribute__((aligned(64))) unsigned int conv_zero_page[16];
 
 // LDS-DMA: 16 bytes per lane from `src` to (wave-uniform) `lds_dst` + lane*16.  The builtin exists
 // only in the device pass; the host pass just needs the kernel's signature.
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const T* zero = reinterpret_cast<const T*>(unetk_zero_page);
+  const T* zero = reinterpret_cast<const T*>(conv_zero_page);
   auto issue_halo = [&](int ch) {
     char* dst = lds + (ch & 1) * HBUF;
     const int c0 = ch * KC;

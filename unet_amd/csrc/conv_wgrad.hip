@@ -2,23 +2,32 @@
 //
 //   dw[co,ci,ky,kx] = sum_{b,y,x} dy[b,y,x,co] * in[b,y+ky-1,x+kx-1,ci]
 //
-// GEMM view: M = Cout, N = taps*Cin, K = pixels.  Both operands are stored
-// pixel-major (NHWC), i.e. K is the slow axis of both, while an MFMA fragment wants
-// K contiguous per lane.  For bf16 the fragments are therefore read from LDS with the
-// transposing ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group); the f32
-// MFMA (16x16x4) takes one element per lane and needs no transpose.
+// GEMM view: M = Cout, N = taps*Cin, K = pixels.  Both operands are stored pixel-major (NHWC),
+// i.e. K is the slow axis of both, while an MFMA fragment wants K contiguous per lane.  For bf16
+// the fragments are therefore read from LDS with the transposing ds_read_b64_tr_b16 (4 pixels x
+// 16 channels per 16-lane group); the f32 MFMA (16x16x4) takes one element per lane and needs no
+// transpose.
 //
-// A workgroup (4 waves) owns BM = MT*16 output channels x one 32-channel input chunk x
-// all taps, and walks a strided list of pixel tiles (TR x TW pixels, TR*TW*sizeof(T)
-// = 512 B... 256 px bf16 / 128 px f32).  Per tile the dy tile and the input halo of the
-// chunk are staged in LDS once; every tap is a shifted window of the same halo.
-// Waves split the work as (16-channel half of the chunk) x (even/odd k-steps), and
-// each wave writes its own fp32 partial into a slab [2*S][Co_pad][taps][Ci_pad];
-// a second kernel sums the slabs in a fixed order (bitwise reproducible, no atomics)
-// and writes the [Co][Ci][KS][KS] fp32 gradient.
+// A workgroup (8 waves) owns BM = MT*16 output channels x KCI = NWN*16 input channels x all taps
+// and walks a strided list of pixel tiles (TR x TW pixels: 256 px bf16 / 128 px f32).  The dy tile
+// and the input halo of a tile are brought in by LDS-DMA (global_load_lds) into a double buffer:
+// tile k+1 is in flight while tile k is multiplied, one barrier per tile.  Every tap is a shifted
+// window of the same halo.  Waves split the work as (16-channel slice of the input chunk) x
+// (k-step residue); each k-residue writes its own fp32 partial into a slab
+// [NWK*S][Co_pad][taps][Ci_pad]; a second kernel sums the slabs in a fixed order (bitwise
+// reproducible, no atomics) and writes the [Co][Ci][KS][KS] fp32 gradient.
 #include "common.h"
 
 namespace {
+
+// page of zeros that out-of-image pixels and channel padding load
+__device__ __attribute__((aligned(64))) unsigned int wgrad_zero_page[16];
+
+__device__ __forceinline__ void glds16(const void* src, char* lds_dst) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_global_load_lds(src, LDS_PTR(void, lds_dst), 16, 0, 0);
+#endif
+}
 
 struct WgradArgs {
   const void* in;
@@ -30,9 +39,6 @@ struct WgradArgs {
   int tiles_x, tiles_y, ntiles, nsplit;
 };
 
-constexpr int row_bytes_bf16(int bytes) { return ((bytes + 31) / 64) * 64 + 32; }   // == 32 mod 64
-constexpr int row_bytes_f32(int bytes) { return ((bytes + 63) / 128) * 128 + 64; }  // == 64 mod 128
-
 __device__ __forceinline__ bf16x8 tr_read8(const char* p0, const char* p1) {
   short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, p0));
   short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, p1));
@@ -41,31 +47,46 @@ __device__ __forceinline__ bf16x8 tr_read8(const char* p0, const char* p1) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
-template <typename T, int MT, int TW, int KS>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+// Slot swizzle of the (unpadded, lane-linear) halo image.  A transposing read touches, per
+// 32-lane half, the rows {o..o+3, o+8..o+11} at one 32-byte column unit; XORing the unit index
+// with row bits 1 and 3 (128-byte rows) or bit 3 (64-byte rows) spreads those eight rows over
+// eight distinct 32-byte units of the 256-byte bank row: conflict-free.
+template <int ROW_BYTES> __device__ __forceinline__ int hswz(int row, int slot16) {
+  if (ROW_BYTES == 64) return slot16 ^ (((row >> 3) & 1) << 1);
+  if (ROW_BYTES == 128) return slot16 ^ ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1);
+  return slot16;
+}
+
+template <typename T, int MT, int TW, int KS, int NWN>
+__global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
   constexpr bool BF = sizeof(T) == 2;
   constexpr int EPP = 16 / (int)sizeof(T);
   constexpr int TPIX = BF ? 256 : 128;          // pixels per tile
   constexpr int TR = TPIX / TW;
   constexpr int BM = MT * 16;
-  constexpr int KCI = 32;                       // input channels per block
+  constexpr int NWK = 8 / NWN;                  // k-step residues (waves along K)
+  constexpr int KCI = NWN * 16;                 // input channels per workgroup
   constexpr int TAPS = KS * KS;
   constexpr int HW_ = (KS == 3) ? TW + 2 : TW;  // halo width
   constexpr int HH_ = (KS == 3) ? TR + 2 : TR;
-  constexpr int RBD = BF ? row_bytes_bf16(BM * 2) : row_bytes_f32(BM * 4);
-  constexpr int RBH = BF ? row_bytes_bf16(KCI * 2) : row_bytes_f32(KCI * 4);
-  constexpr int PPD = BM / EPP;                 // 16-byte parts per dy row
-  constexpr int PPH = KCI / EPP;
-  __shared__ __attribute__((aligned(16))) char lds[TPIX * RBD + HH_ * HW_ * RBH];
-  char* lds_dy = lds;
-  char* lds_h = lds + TPIX * RBD;
+  constexpr int HPIX = HH_ * HW_;
+  constexpr int RBD = BM * (int)sizeof(T);      // dy row bytes (96 B for 48 bf16 channels: conflict-free as is)
+  constexpr int RBH = KCI * (int)sizeof(T);     // halo row bytes
+  constexpr int PPD = RBD / 16, PPH = RBH / 16;
+  constexpr int DINSTR = (TPIX * PPD + 63) / 64, HINSTR = (HPIX * PPH + 63) / 64;
+  constexpr int DBUF = DINSTR * 1024, HBUF = HINSTR * 1024;
+  constexpr int KSTEP_PIX = BF ? 32 : 4;
+  constexpr int NKS = TPIX / KSTEP_PIX;
+  __shared__ __attribute__((aligned(1024))) char lds[2 * (DBUF + HBUF)];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wn = wave & 1, wk = wave >> 1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave % NWN, wk = wave / NWN;
   const int ci0 = blockIdx.x * KCI;
   const int co0 = blockIdx.y * BM;
   const T* in = reinterpret_cast<const T*>(a.in);
   const T* dy = reinterpret_cast<const T*>(a.dy);
+  const T* zero = reinterpret_cast<const T*>(wgrad_zero_page);
 
   f32x4 acc[MT][TAPS];
 #pragma unroll
@@ -75,45 +96,54 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 
   const int g = lane >> 4, li = lane & 15, q = li >> 2, p4 = li & 3;
 
-  for (int tile = blockIdx.z; tile < a.ntiles; tile += a.nsplit) {
+  auto issue_tile = [&](int tile, int buf) {
     int t = tile;
     const int tx = t % a.tiles_x;
     t /= a.tiles_x;
     const int ty = t % a.tiles_y;
     const int b = t / a.tiles_y;
     const int y0 = ty * TR, x0 = tx * TW;
-    __syncthreads();
-    // dy tile: [pixel][BM channels]
-    for (int idx = tid; idx < TPIX * PPD; idx += 256) {
-      const int pix = idx / PPD, part = idx - pix * PPD;
+    char* dbuf = lds + buf * (DBUF + HBUF);
+    char* hbuf = dbuf + DBUF;
+    for (int i = wave; i < DINSTR; i += 8) {      // dy tile: [pixel][BM channels]
+      const int part = i * 64 + lane;
+      const int pix = part / PPD, slot = part - pix * PPD;
       const int tr = pix / TW, tc = pix - tr * TW;
       const int gy = y0 + tr, gx = x0 + tc;
-      const int c = co0 + part * EPP;
-      Vec16<T> v = zero16<T>();
-      if (gy < a.H && gx < a.W && c < a.Co)
-        v = load16(dy + (((long)b * a.H + gy) * a.W + gx) * a.lddy + c);
-      store16(reinterpret_cast<T*>(lds_dy + pix * RBD + part * 16), v);
+      const int c = co0 + slot * EPP;
+      const T* src = zero;
+      if (pix < TPIX && gy < a.H && gx < a.W && c < a.Co)
+        src = dy + (((long)b * a.H + gy) * a.W + gx) * a.lddy + c;
+      glds16(src, dbuf + i * 1024);
     }
-    // input halo: [(TR+2)*(TW+2) pixels][32 channels]
-    for (int idx = tid; idx < HH_ * HW_ * PPH; idx += 256) {
-      const int pix = idx / PPH, part = idx - pix * PPH;
+    for (int i = wave; i < HINSTR; i += 8) {      // input halo: [(TR+2)*(TW+2) pixels][KCI channels]
+      const int part = i * 64 + lane;
+      const int pix = part / PPH, slot = part - pix * PPH;
       const int hy = pix / HW_, hx = pix - hy * HW_;
       const int gy = y0 + hy - (KS == 3 ? 1 : 0), gx = x0 + hx - (KS == 3 ? 1 : 0);
-      const int c = ci0 + part * EPP;
-      Vec16<T> v = zero16<T>();
-      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.Ci)
-        v = load16(in + (((long)b * a.H + gy) * a.W + gx) * a.ldin + c);
-      store16(reinterpret_cast<T*>(lds_h + pix * RBH + part * 16), v);
+      const int c = ci0 + hswz<RBH>(pix, slot) * EPP;
+      const T* src = zero;
+      if (pix < HPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.Ci)
+        src = in + (((long)b * a.H + gy) * a.W + gx) * a.ldin + c;
+      glds16(src, hbuf + i * 1024);
     }
-    __syncthreads();
+  };
+
+  int it = 0;
+  if (blockIdx.z < a.ntiles) issue_tile(blockIdx.z, 0);
+#pragma unroll 1
+  for (int tile = blockIdx.z; tile < a.ntiles; tile += a.nsplit, ++it) {
+    __syncthreads();     // this tile has landed for every wave; everyone is done with the previous one
+    if (tile + a.nsplit < a.ntiles) issue_tile(tile + a.nsplit, (it + 1) & 1);
+    const char* lds_dy = lds + (it & 1) * (DBUF + HBUF);
+    const char* lds_h = lds_dy + DBUF;
 
     if constexpr (BF) {
-      // k-step = 32 consecutive tile pixels; this wave takes steps wk, wk+2, ...
+      // k-step = 32 consecutive tile pixels; this wave takes steps wk, wk+NWK, ...
 #pragma unroll 1
-      for (int ks = wk; ks < TPIX / 32; ks += 2) {
-        // the two 4-pixel groups this lane addresses for the transposing read
-        const int pk0 = ks * 32 + 8 * g + q;      // rows q of block kk=0
-        const int pk1 = pk0 + 4;                  // block kk=1
+      for (int ks = wk; ks < NKS; ks += NWK) {
+        const int pk0 = ks * 32 + 8 * g + q;      // the row (pixel) this lane addresses in block kk=0
+        const int pk1 = pk0 + 4;                  // ... and in block kk=1
         bf16x8 af[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -121,13 +151,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
                            lds_dy + pk1 * RBD + (m * 16 + 4 * p4) * 2);
         const int r0 = pk0 / TW, c0_ = pk0 - r0 * TW;
         const int r1 = pk1 / TW, c1_ = pk1 - r1 * TW;
+        const int slot = wn * 2 + (p4 >> 1), sub = (p4 & 1) * 8;
 #pragma unroll
         for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
           for (int kx = 0; kx < KS; ++kx) {
-            const char* h0 = lds_h + ((r0 + ky) * HW_ + c0_ + kx) * RBH + (wn * 16 + 4 * p4) * 2;
-            const char* h1 = lds_h + ((r1 + ky) * HW_ + c1_ + kx) * RBH + (wn * 16 + 4 * p4) * 2;
-            const bf16x8 bfr = tr_read8(h0, h1);
+            const int h0r = (r0 + ky) * HW_ + c0_ + kx, h1r = (r1 + ky) * HW_ + c1_ + kx;
+            const bf16x8 bfr = tr_read8(lds_h + h0r * RBH + hswz<RBH>(h0r, slot) * 16 + sub,
+                                        lds_h + h1r * RBH + hswz<RBH>(h1r, slot) * 16 + sub);
 #pragma unroll
             for (int m = 0; m < MT; ++m)
               acc[m][ky * KS + kx] =
@@ -137,19 +168,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     } else {
       // k-step = 4 consecutive tile pixels; A[m=lane&15][k=lane>>4], B[k=lane>>4][n=lane&15]
 #pragma unroll 1
-      for (int ks = wk; ks < TPIX / 4; ks += 2) {
+      for (int ks = wk; ks < NKS; ks += NWK) {
         const int pk = ks * 4 + g;
         const int r0 = pk / TW, c0_ = pk - r0 * TW;
         float af[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
           af[m] = *reinterpret_cast<const float*>(lds_dy + pk * RBD + (m * 16 + li) * 4);
+        const int byte = (wn * 16 + li) * 4;
 #pragma unroll
         for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
           for (int kx = 0; kx < KS; ++kx) {
-            const float bv = *reinterpret_cast<const float*>(
-                lds_h + ((r0 + ky) * HW_ + c0_ + kx) * RBH + (wn * 16 + li) * 4);
+            const int hr = (r0 + ky) * HW_ + c0_ + kx;
+            const float bv = *reinterpret_cast<const float*>(lds_h + hr * RBH + hswz<RBH>(hr, byte >> 4) * 16 +
+                                                             (byte & 15));
 #pragma unroll
             for (int m = 0; m < MT; ++m)
               acc[m][ky * KS + kx] =
@@ -159,8 +192,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     }
   }
 
-  // slab[(2*z + wk)][co][tap][ci]; C layout: col (ci) = lane&15, row (co) = 4*(lane>>4)+r
-  float* slab = a.slab + (long)(2 * blockIdx.z + wk) * a.Co_pad * TAPS * a.Ci_pad;
+  // slab[(NWK*z + wk)][co][tap][ci]; C layout: col (ci) = lane&15, row (co) = 4*(lane>>4)+r
+  float* slab = a.slab + (long)(NWK * blockIdx.z + wk) * a.Co_pad * TAPS * a.Ci_pad;
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -204,23 +237,27 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 struct WgradPlan {
-  int mt, tw, tpix, tr, tiles_x, tiles_y, ntiles, nsplit, Co_pad, Ci_pad;
+  int mt, tw, nwn, nwk, tpix, tr, tiles_x, tiles_y, ntiles, nsplit, Co_pad, Ci_pad;
 };
 
 WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int dtype) {
   WgradPlan p;
   p.mt = (Co % 48 == 0) ? 3 : ((Co % 64 == 0 || Co > 48) ? 4 : (Co > 32 ? 3 : 2));
   p.tw = (W <= 16) ? 16 : 32;
+  // 64 input channels per workgroup when that wastes no padding, else 32
+  p.nwn = (dtype == UNETK_BF16 && (Ci % 64 == 0 || (Ci > 256 && (Ci % 64) > 32))) ? 4 : 2;
+  p.nwk = 8 / p.nwn;
   p.tpix = dtype == UNETK_BF16 ? 256 : 128;
   p.tr = p.tpix / p.tw;
   p.tiles_x = cdiv(W, p.tw);
   p.tiles_y = cdiv(H, p.tr);
   p.ntiles = B * p.tiles_x * p.tiles_y;
   p.Co_pad = cdiv(Co, p.mt * 16) * p.mt * 16;
-  p.Ci_pad = cdiv(Ci, 32) * 32;
-  const int gxy = (p.Ci_pad / 32) * (p.Co_pad / (p.mt * 16));
-  int s = 1536 / gxy;
-  if (s > 256) s = 256;
+  const int kci = p.nwn * 16;
+  p.Ci_pad = cdiv(Ci, kci) * kci;
+  const int gxy = (p.Ci_pad / kci) * (p.Co_pad / (p.mt * 16));
+  int s = 768 / gxy;                       // one workgroup per CU: aim at ~3 rounds of 256
+  if (s * p.nwk > 512) s = 512 / p.nwk;    // bound the number of partial slabs
   if (s < 1) s = 1;
   if (s > p.ntiles) s = p.ntiles;
   p.nsplit = s;
@@ -229,16 +266,19 @@ WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int dtype) {
 
 template <typename T, int KS>
 int launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t stream) {
-  dim3 grid(p.Ci_pad / 32, p.Co_pad / (p.mt * 16), p.nsplit);
-#define WG_CASE(MT_, TW_)                                                                         \
-  if (p.mt == MT_ && p.tw == TW_) {                                                               \
-    hipLaunchKernelGGL((conv_wgrad_kernel<T, MT_, TW_, KS>), grid, dim3(256), 0, stream, a);      \
-    UNETK_CHECK_LAUNCH();                                                                         \
-    return UNETK_OK;                                                                              \
+  dim3 grid(p.Ci_pad / (p.nwn * 16), p.Co_pad / (p.mt * 16), p.nsplit);
+#define WG_CASE(MT_, TW_, NWN_)                                                                        \
+  if (p.mt == MT_ && p.tw == TW_ && p.nwn == NWN_) {                                                   \
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, MT_, TW_, KS, NWN_>), grid, dim3(512), 0, stream, a);     \
+    UNETK_CHECK_LAUNCH();                                                                              \
+    return UNETK_OK;                                                                                   \
   }
-  WG_CASE(2, 16) WG_CASE(2, 32) WG_CASE(3, 16) WG_CASE(3, 32) WG_CASE(4, 16) WG_CASE(4, 32)
+  WG_CASE(2, 16, 2) WG_CASE(2, 32, 2) WG_CASE(3, 16, 2) WG_CASE(3, 32, 2) WG_CASE(4, 16, 2) WG_CASE(4, 32, 2)
+  if constexpr (sizeof(T) == 2) {   // 64-channel chunks only fit LDS with 2-byte elements
+    WG_CASE(2, 16, 4) WG_CASE(2, 32, 4) WG_CASE(3, 16, 4) WG_CASE(3, 32, 4) WG_CASE(4, 16, 4) WG_CASE(4, 32, 4)
+  }
 #undef WG_CASE
-  unetk_set_error("conv_wgrad: no kernel for mt=%d tw=%d", p.mt, p.tw);
+  unetk_set_error("conv_wgrad: no kernel for mt=%d tw=%d nwn=%d", p.mt, p.tw, p.nwn);
   return UNETK_EINVAL;
 }
 
@@ -248,7 +288,7 @@ extern "C" {
 
 int64_t unetk_conv_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Co, int ks, int dtype) {
   const WgradPlan p = plan_wgrad(B, H, W, Ci, Co, dtype);
-  return (int64_t)2 * p.nsplit * p.Co_pad * ks * ks * p.Ci_pad * 4;
+  return (int64_t)p.nwk * p.nsplit * p.Co_pad * ks * ks * p.Ci_pad * 4;
 }
 
 int unetk_conv_wgrad(const void* in, int ldin, const void* dy, int lddy, float* dw, int B, int H, int W,
@@ -277,7 +317,7 @@ int unetk_conv_wgrad(const void* in, int ldin, const void* dy, int lddy, float* 
   if (rc != UNETK_OK) return rc;
   const long nblocks = (long)Co * ks * ks * (p.Ci_pad / 32);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)nblocks), dim3(256), 0, stream, a.slab, dw,
-                     2 * p.nsplit, Co, Ci, p.Co_pad, p.Ci_pad, ks * ks, accumulate);
+                     p.nwk * p.nsplit, Co, Ci, p.Co_pad, p.Ci_pad, ks * ks, accumulate);
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }
