@@ -37,7 +37,11 @@ struct WgradArgs {
   int B, H, W, Ci, Co;
   int Ci_pad, Co_pad;
   int tiles_x, tiles_y, ntiles, nsplit;
+  int gx, gy;               // workgroups along Ci and Co
 };
+
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 __device__ __forceinline__ bf16x8 tr_read8(const char* p0, const char* p1) {
   short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, p0));
@@ -77,13 +81,26 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
   constexpr int DBUF = DINSTR * 1024, HBUF = HINSTR * 1024;
   constexpr int KSTEP_PIX = BF ? 32 : 4;
   constexpr int NKS = TPIX / KSTEP_PIX;
-  __shared__ __attribute__((aligned(1024))) char lds[2 * (DBUF + HBUF)];
+  // Two separate LDS objects (not one array indexed by parity): the compiler then knows that the
+  // DMA filling one buffer cannot alias the reads of the other and leaves it in flight during the
+  // multiply instead of waiting for it before the first LDS read.
+  __shared__ __attribute__((aligned(1024))) char buf0[DBUF + HBUF];
+  __shared__ __attribute__((aligned(1024))) char buf1[DBUF + HBUF];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave % NWN, wk = wave / NWN;
-  const int ci0 = blockIdx.x * KCI;
-  const int co0 = blockIdx.y * BM;
+  // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  The (ci chunk, co
+  // block) workgroups of one pixel-tile list share every dy tile and halo, so they are given
+  // linear ids that differ by multiples of 8: same XCD, dispatched back to back, and the
+  // re-reads hit that XCD's L2 instead of HBM.
+  const int gxy = a.gx * a.gy;
+  const int lin = blockIdx.x;
+  const bool xcd_map = (a.nsplit & 7) == 0;
+  const int cxy = xcd_map ? (lin >> 3) % gxy : lin % gxy;
+  const int bz = xcd_map ? ((lin >> 3) / gxy) * 8 + (lin & 7) : lin / gxy;
+  const int ci0 = (cxy % a.gx) * KCI;
+  const int co0 = (cxy / a.gx) * BM;
   const T* in = reinterpret_cast<const T*>(a.in);
   const T* dy = reinterpret_cast<const T*>(a.dy);
   const T* zero = reinterpret_cast<const T*>(wgrad_zero_page);
@@ -96,14 +113,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
 
   const int g = lane >> 4, li = lane & 15, q = li >> 2, p4 = li & 3;
 
-  auto issue_tile = [&](int tile, int buf) {
+  auto issue_tile = [&](int tile, char* dbuf) {
     int t = tile;
     const int tx = t % a.tiles_x;
     t /= a.tiles_x;
     const int ty = t % a.tiles_y;
     const int b = t / a.tiles_y;
     const int y0 = ty * TR, x0 = tx * TW;
-    char* dbuf = lds + buf * (DBUF + HBUF);
     char* hbuf = dbuf + DBUF;
     for (int i = wave; i < DINSTR; i += 8) {      // dy tile: [pixel][BM channels]
       const int part = i * 64 + lane;
@@ -129,15 +145,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
     }
   };
 
-  int it = 0;
-  if (blockIdx.z < a.ntiles) issue_tile(blockIdx.z, 0);
-#pragma unroll 1
-  for (int tile = blockIdx.z; tile < a.ntiles; tile += a.nsplit, ++it) {
-    __syncthreads();     // this tile has landed for every wave; everyone is done with the previous one
-    if (tile + a.nsplit < a.ntiles) issue_tile(tile + a.nsplit, (it + 1) & 1);
-    const char* lds_dy = lds + (it & 1) * (DBUF + HBUF);
+  auto multiply = [&](const char* lds_dy) {
     const char* lds_h = lds_dy + DBUF;
-
     if constexpr (BF) {
       // k-step = 32 consecutive tile pixels; this wave takes steps wk, wk+NWK, ...
 #pragma unroll 1
@@ -150,20 +159,38 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
           af[m] = tr_read8(lds_dy + pk0 * RBD + (m * 16 + 4 * p4) * 2,
                            lds_dy + pk1 * RBD + (m * 16 + 4 * p4) * 2);
         const int r0 = pk0 / TW, c0_ = pk0 - r0 * TW;
-        const int r1 = pk1 / TW, c1_ = pk1 - r1 * TW;
         const int slot = wn * 2 + (p4 >> 1), sub = (p4 & 1) * 8;
+        // A lane's eight k-slots are eight consecutive pixels of one image row, so the three
+        // horizontal taps are the 8-pixel windows at offsets 0, 1, 2 of a 12-pixel run: three
+        // transposing reads per kernel row, the windows cut out of them in registers.
 #pragma unroll
-        for (int ky = 0; ky < KS; ++ky)
+        for (int ky = 0; ky < KS; ++ky) {
+          const int hr = (r0 + ky) * HW_ + c0_;
+          u32x2 t[KS == 3 ? 3 : 2];
+#pragma unroll
+          for (int i = 0; i < (KS == 3 ? 3 : 2); ++i) {
+            const int row = hr + 4 * i;
+            t[i] = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(
+                                                 short4v, lds_h + row * RBH + hswz<RBH>(row, slot) * 16 + sub)));
+          }
+          u32x4 win[KS];
+          win[0] = u32x4{t[0][0], t[0][1], t[1][0], t[1][1]};
+          if constexpr (KS == 3) {
+            win[1] = u32x4{__builtin_amdgcn_alignbit(t[0][1], t[0][0], 16),
+                           __builtin_amdgcn_alignbit(t[1][0], t[0][1], 16),
+                           __builtin_amdgcn_alignbit(t[1][1], t[1][0], 16),
+                           __builtin_amdgcn_alignbit(t[2][0], t[1][1], 16)};
+            win[2] = u32x4{t[0][1], t[1][0], t[1][1], t[2][0]};
+          }
 #pragma unroll
           for (int kx = 0; kx < KS; ++kx) {
-            const int h0r = (r0 + ky) * HW_ + c0_ + kx, h1r = (r1 + ky) * HW_ + c1_ + kx;
-            const bf16x8 bfr = tr_read8(lds_h + h0r * RBH + hswz<RBH>(h0r, slot) * 16 + sub,
-                                        lds_h + h1r * RBH + hswz<RBH>(h1r, slot) * 16 + sub);
+            const bf16x8 bfr = __builtin_bit_cast(bf16x8, win[kx]);
 #pragma unroll
             for (int m = 0; m < MT; ++m)
               acc[m][ky * KS + kx] =
                   __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr, acc[m][ky * KS + kx], 0, 0, 0);
           }
+        }
       }
     } else {
       // k-step = 4 consecutive tile pixels; A[m=lane&15][k=lane>>4], B[k=lane>>4][n=lane&15]
@@ -190,10 +217,23 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
           }
       }
     }
+  };
+
+  // tile k+1 is in flight while tile k is multiplied; one barrier per tile
+  if (bz < a.ntiles) issue_tile(bz, buf0);
+#pragma unroll 1
+  for (int tile = bz; tile < a.ntiles; tile += 2 * a.nsplit) {
+    __syncthreads();     // buf0 has landed for every wave; everyone is done reading buf1
+    if (tile + a.nsplit < a.ntiles) issue_tile(tile + a.nsplit, buf1);
+    multiply(buf0);
+    if (tile + a.nsplit >= a.ntiles) break;
+    __syncthreads();
+    if (tile + 2 * a.nsplit < a.ntiles) issue_tile(tile + 2 * a.nsplit, buf0);
+    multiply(buf1);
   }
 
   // slab[(NWK*z + wk)][co][tap][ci]; C layout: col (ci) = lane&15, row (co) = 4*(lane>>4)+r
-  float* slab = a.slab + (long)(NWK * blockIdx.z + wk) * a.Co_pad * TAPS * a.Ci_pad;
+  float* slab = a.slab + (long)(NWK * bz + wk) * a.Co_pad * TAPS * a.Ci_pad;
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -260,13 +300,14 @@ WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int dtype) {
   if (s * p.nwk > 512) s = 512 / p.nwk;    // bound the number of partial slabs
   if (s < 1) s = 1;
   if (s > p.ntiles) s = p.ntiles;
+  if (s >= 32) s &= ~7;                    // multiples of 8 enable the XCD-aware workgroup order
   p.nsplit = s;
   return p;
 }
 
 template <typename T, int KS>
 int launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t stream) {
-  dim3 grid(p.Ci_pad / (p.nwn * 16), p.Co_pad / (p.mt * 16), p.nsplit);
+  dim3 grid((unsigned)(a.gx * a.gy * p.nsplit));
 #define WG_CASE(MT_, TW_, NWN_)                                                                        \
   if (p.mt == MT_ && p.tw == TW_ && p.nwn == NWN_) {                                                   \
     hipLaunchKernelGGL((conv_wgrad_kernel<T, MT_, TW_, KS, NWN_>), grid, dim3(512), 0, stream, a);     \
@@ -309,6 +350,7 @@ int unetk_conv_wgrad(const void* in, int ldin, const void* dy, int lddy, float* 
   a.in = in; a.dy = dy; a.slab = (float*)workspace; a.ldin = ldin; a.lddy = lddy;
   a.B = B; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.Ci_pad = p.Ci_pad; a.Co_pad = p.Co_pad;
   a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.ntiles = p.ntiles; a.nsplit = p.nsplit;
+  a.gx = p.Ci_pad / (p.nwn * 16); a.gy = p.Co_pad / (p.mt * 16);
   int rc;
   if (dtype == UNETK_BF16)
     rc = ks == 3 ? launch_wgrad<bf16, 3>(a, p, stream) : launch_wgrad<bf16, 1>(a, p, stream);

@@ -7,6 +7,7 @@ network runs as one ``torch.autograd.Function``: activations are NHWC in the com
 (float32, or bfloat16 with fp32 accumulation), convolutions are MFMA implicit GEMMs with the
 BatchNorm statistics taken in their epilogue, and BatchNorm+ReLU+Dropout2d+MaxPool are one pass.
 """
+import os
 from typing import List, Optional
 
 import torch
@@ -94,6 +95,20 @@ class OptimizedUNet(nn.Module):
                 keep = torch.empty((B, c), dtype=torch.float32, device=device).bernoulli_(1 - p)
                 masks.append(keep.div_(1 - p))
         return masks
+
+
+OVERLAP_WGRAD = os.environ.get("UNETK_OVERLAP_WGRAD", "1") != "0"
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = torch.device(device).index
+    if key is None:
+        key = torch.cuda.current_device()
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+    return st
 
 
 def _pack_all(model, dt, transpose):
@@ -207,6 +222,12 @@ class _UNetTrainFn(torch.autograd.Function):
         dt = model.compute_dtype
         pkT = _pack_all(model, dt, True)
         grads = {}
+        # Weight gradients are off the critical chain (dgrad -> BatchNorm backward -> dgrad ...):
+        # they run on a second HIP stream so the MFMA-bound wgrad kernels overlap the HBM-bound
+        # BatchNorm / pool / resize backward passes of the following layers.
+        main = torch.cuda.current_stream()
+        side = _side_stream(dout.device) if OVERLAP_WGRAD else main
+        held = []          # operands of side-stream kernels stay allocated until the join
 
         # final 1x1 conv
         units_d1, a_d1, _ = saved["decoder1"]
@@ -223,8 +244,17 @@ class _UNetTrainFn(torch.autograd.Function):
                                                    keep if u == 1 else None, relu=True)
                 grads[f"{name}.{bi}.weight"], grads[f"{name}.{bi}.bias"] = dgamma, dbeta
                 conv = seq[ci]
-                grads[f"{name}.{ci}.weight"] = ops.conv_wgrad(t_in, dy, conv.in_channels,
-                                                              conv.out_channels, 3)
+                if side is main:
+                    dw = ops.conv_wgrad(t_in, dy, conv.in_channels, conv.out_channels, 3)
+                else:
+                    ready = torch.cuda.Event()
+                    ready.record(main)
+                    held.append(dy)
+                    with torch.cuda.stream(side):
+                        side.wait_event(ready)
+                        dw = ops.conv_wgrad(t_in, dy, conv.in_channels, conv.out_channels, 3)
+                    dw.record_stream(main)
+                grads[f"{name}.{ci}.weight"] = dw
                 if u == 1 or need_dx:
                     g, _ = ops.conv_fwd(dy, pkT[(name, ci)])
                 else:
@@ -250,6 +280,9 @@ class _UNetTrainFn(torch.autograd.Function):
         dx = None
         if ctx.need_dx:
             dx = ops.nhwc_to_nchw(g, ctx.in_shape[1])
+        if side is not main:
+            main.wait_stream(side)
+        held.clear()
         ctx.saved = None
         out_grads = []
         for n, p in model.named_parameters():
