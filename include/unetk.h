@@ -68,8 +68,9 @@ int unetk_nhwc_to_nchw(const void* src, int ld, float* dst, int B, int C, int H,
                        unetk_stream_t stream);
 
 /* ---- BatchNorm2d + ReLU + Dropout2d mask + MaxPool2d(2,2) ---------------------------
- * training.py:525-530 and :464-473; swin_unet_model.py:513-517, 609-610. */
-int unetk_bn_finalize(const float* partials, int nparts, int C, int64_t count, const float* gamma,
+ * training.py:525-530 and :464-473; swin_unet_model.py:513-517, 609-610.
+ * unetk_bn_finalize consumes `partials` (long lists are first reduced in place). */
+int unetk_bn_finalize(float* partials, int nparts, int C, int64_t count, const float* gamma,
                       const float* beta, float eps, float momentum, float* running_mean,
                       float* running_var, float* mean, float* invstd, float* scale, float* shift,
                       unetk_stream_t stream);

@@ -30,3 +30,11 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
     return load
+
+
+@pytest.fixture(autouse=True)
+def _seed_torch():
+    """Every test draws its unseeded torch randoms from the same stream: failures reproduce."""
+    import torch
+    torch.manual_seed(20240601)
+    yield

@@ -49,6 +49,8 @@ struct ConvArgs {
   int nchunks;
   int act;                 // 0 none, 1 relu, 2 gelu(erf)
   int tiles_x, tiles_y;
+  int ntiles, tiles_per_xcd;   // workgroup order: see the kernel
+  int nby;                     // channel blocks
 };
 
 constexpr int ROWB = 64;   // LDS bytes per staged row (unpadded, slots swizzled: see swz())
@@ -59,8 +61,8 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
-template <typename T, int NT, int KS>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+template <typename T, int NT, int KS, bool HDB>
+__device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
   using M = MMA<T>;
   constexpr int KC = M::KC;
   constexpr int EPP = 16 / (int)sizeof(T);     // elements per 16-byte part
@@ -78,7 +80,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   constexpr int WINSTR = (WROWS * 4) / 64;              // per weight slab (BN multiple of 16: exact)
   static_assert((WROWS * 4) % 64 == 0, "weight slab must be whole wave instructions");
   constexpr int HBUF = HINSTR * 1024, WBUF = WINSTR * 1024;
-  constexpr int MAIN_BYTES = 2 * HBUF + 2 * WBUF;
+  constexpr int NHB = HDB ? 2 : 1;                      // halo buffers
+  constexpr int MAIN_BYTES = NHB * HBUF + 2 * WBUF;
   constexpr int STAGE_BYTES = 4 * 16 * BN * (int)sizeof(T);
   constexpr int RED_BYTES = 4 * 2 * BN * (int)sizeof(float);
   constexpr int LDS_BYTES = MAIN_BYTES > STAGE_BYTES + RED_BYTES ? MAIN_BYTES : STAGE_BYTES + RED_BYTES;
@@ -89,7 +92,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nb = blockIdx.y;
+  // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  XCD x takes the x-th
+  // contiguous eighth of the tile list and walks it with the channel block as the fast index, so
+  // the channel blocks of a tile (same input halo) and neighbouring tiles (shared halo rows and
+  // columns) are resident together under one L2.
+  const int xcd = blockIdx.x & 7;
+  const int item = blockIdx.x >> 3;
+  const int nb = item % a.nby;
+  const int tile = xcd * a.tiles_per_xcd + item / a.nby;
+  if (item / a.nby >= a.tiles_per_xcd || tile >= a.ntiles) return;
   const int n0 = nb * BN;
   const T* in = reinterpret_cast<const T*>(a.in);
   const T* wp = reinterpret_cast<const T*>(a.w);
@@ -100,7 +111,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   long p0 = 0;                       // first flat pixel (1x1 mode)
   const long npix = (long)a.B * a.H * a.W;
   if (KS == 3) {
-    int t = blockIdx.x;
+    int t = tile;
     int tx = t % a.tiles_x;
     t /= a.tiles_x;
     int ty = t % a.tiles_y;
@@ -108,7 +119,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     y0 = ty * 16;
     x0 = tx * 16;
   } else {
-    p0 = (long)blockIdx.x * 256;
+    p0 = (long)tile * 256;
   }
 
   f32x4 acc[4][NT];
@@ -119,7 +130,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
   const T* zero = reinterpret_cast<const T*>(conv_zero_page);
   auto issue_halo = [&](int ch) {
-    char* dst = lds + (ch & 1) * HBUF;
+    char* dst = lds + (HDB ? (ch & 1) : 0) * HBUF;
     const int c0 = ch * KC;
     for (int i = wave; i < HINSTR; i += 4) {
       const int part = i * 64 + lane;
@@ -140,7 +151,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   };
   auto issue_w = [&](int phase) {
     const int ch = phase / KS, ky = phase - ch * KS;
-    char* dst = lds + 2 * HBUF + (phase & 1) * WBUF;
+    char* dst = lds + NHB * HBUF + (phase & 1) * WBUF;
     const T* wsrc = wp + ((((long)nb * a.nchunks + ch) * TAPS + ky * KS) * BN) * KC;
     for (int i = wave; i < WINSTR; i += 4) {
       const int part = i * 64 + lane;
@@ -157,12 +168,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int ch = phase / KS, ky = phase - ch * KS;
     // the DMA of this phase has landed for every wave, and everyone is done with phase-1's buffers
     __syncthreads();
+    if (!HDB && ky == 0 && ch > 0) {
+      // single halo buffer (more workgroups per CU instead): the chunk is fetched only now that
+      // every wave is done with the previous one; other workgroups on the CU cover the wait
+      issue_halo(ch);
+      __syncthreads();
+    }
     if (phase + 1 < nphase) {
       issue_w(phase + 1);
-      if (ky == KS - 1) issue_halo(ch + 1);
+      if (HDB && ky == KS - 1) issue_halo(ch + 1);
     }
-    const char* lds_halo = lds + (ch & 1) * HBUF;
-    const char* lds_w = lds + 2 * HBUF + (phase & 1) * WBUF;
+    const char* lds_halo = lds + (HDB ? (ch & 1) : 0) * HBUF;
+    const char* lds_w = lds + NHB * HBUF + (phase & 1) * WBUF;
 #pragma unroll
     for (int kx = 0; kx < KS; ++kx) {
 #pragma unroll
@@ -241,7 +258,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   if (a.stats != nullptr && tid < BN && n0 + tid < a.Co) {
     const float s = red[0][0][tid] + red[1][0][tid] + red[2][0][tid] + red[3][0][tid];
     const float q = red[0][1][tid] + red[1][1][tid] + red[2][1][tid] + red[3][1][tid];
-    float* st = a.stats + (long)blockIdx.x * 2 * a.Co;
+    float* st = a.stats + (long)tile * 2 * a.Co;
     st[n0 + tid] = s;
     st[a.Co + n0 + tid] = q;
   }
@@ -293,6 +310,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   }
 }
 
+template <typename T, int NT, int KS>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+  conv_igemm_body<T, NT, KS, true>(a);
+}
+
+// Narrow layers move more bytes per flop than the MFMA-bound wide ones: they trade the second halo
+// buffer and registers for four workgroups per CU, so more loads are in flight.
+template <typename T, int NT, int KS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_igemm_occ4_kernel(
+    ConvArgs a) {
+  conv_igemm_body<T, NT, KS, false>(a);
+}
+
 // ---- weight packing: [Co][Ci][KS][KS] f32 -> [nblk][nchunk][tap][BN][KC] T
 template <typename T>
 __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ dst, int Co, int Ci,
@@ -322,12 +352,18 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
 }
 
 template <typename T, int KS>
-int launch_conv(const ConvArgs& a, int bn, hipStream_t stream) {
+int launch_conv(ConvArgs a, int bn, hipStream_t stream) {
   const long npix = (long)a.B * a.H * a.W;
-  dim3 grid;
-  grid.x = (KS == 3) ? a.B * a.tiles_x * a.tiles_y : cdiv(npix, 256);
-  grid.y = cdiv(a.Co, bn);
-  grid.z = 1;
+  a.ntiles = (KS == 3) ? a.B * a.tiles_x * a.tiles_y : (int)cdiv(npix, 256);
+  a.tiles_per_xcd = cdiv(a.ntiles, 8);
+  a.nby = cdiv(a.Co, bn);
+  dim3 grid((unsigned)(8 * a.tiles_per_xcd * a.nby));
+  if (KS == 3 && bn <= 48) {
+    if (bn == 32) hipLaunchKernelGGL((conv_igemm_occ4_kernel<T, 2, KS>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((conv_igemm_occ4_kernel<T, 3, KS>), grid, dim3(256), 0, stream, a);
+    UNETK_CHECK_LAUNCH();
+    return UNETK_OK;
+  }
   switch (bn) {
     case 32: hipLaunchKernelGGL((conv_igemm_kernel<T, 2, KS>), grid, dim3(256), 0, stream, a); break;
     case 48: hipLaunchKernelGGL((conv_igemm_kernel<T, 3, KS>), grid, dim3(256), 0, stream, a); break;

@@ -40,9 +40,27 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict
 }
 
 // ------------------------------------------------------------------ BatchNorm statistics
-// partials: [nparts][2][C] (sum, sum of squares).  One workgroup per 4 channels.
+// First level for long partial lists: workgroup (g, column block) sums rows [g*G, (g+1)*G) of its
+// columns in double and leaves the result in place as a float pair (high part in row g*G, remainder
+// in row g*G+1).  Each thread touches only its own column, reads before it writes.
+__global__ __launch_bounds__(256) void bn_prereduce_kernel(float* partials, int nparts, int ncol, int G) {
+  const int col = blockIdx.y * 256 + threadIdx.x;
+  if (col >= ncol) return;
+  const long r0 = (long)blockIdx.x * G;
+  long r1 = r0 + G;
+  if (r1 > nparts) r1 = nparts;
+  if (r1 - r0 < 2) return;
+  double s = 0.0;
+  for (long r = r0; r < r1; ++r) s += (double)partials[r * ncol + col];
+  const float hi = (float)s;
+  partials[r0 * ncol + col] = hi;
+  partials[(r0 + 1) * ncol + col] = (float)(s - (double)hi);
+}
+
+// partials: [nparts][2][C] (sum, sum of squares).  One workgroup per 4 channels.  With G > 0 only
+// rows g*G and g*G+1 are read (the output of bn_prereduce_kernel).
 __global__ __launch_bounds__(256) void bn_finalize_kernel(
-    const float* __restrict__ partials, int nparts, int C, double count, const float* __restrict__ gamma,
+    const float* __restrict__ partials, int nparts, int G, int C, double count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, float momentum, float* running_mean, float* running_var,
     float* __restrict__ mean_out, float* __restrict__ invstd_out, float* __restrict__ scale_out,
     float* __restrict__ shift_out) {
@@ -50,11 +68,16 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
   const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;
   const int c = blockIdx.x * 4 + cl;
   double s = 0.0, q = 0.0;
-  if (c < C)
-    for (int r = rl; r < nparts; r += 64) {
-      s += (double)partials[((long)r * 2) * C + c];
-      q += (double)partials[((long)r * 2 + 1) * C + c];
+  if (c < C) {
+    const int nrows = G > 0 ? 2 * ((nparts + G - 1) / G) : nparts;
+    for (int i = rl; i < nrows; i += 64) {
+      const long r = G > 0 ? (long)(i >> 1) * G + (i & 1) : i;
+      if (r < nparts) {
+        s += (double)partials[(r * 2) * C + c];
+        q += (double)partials[(r * 2 + 1) * C + c];
+      }
     }
+  }
   red[0][rl][cl] = s;
   red[1][rl][cl] = q;
   __syncthreads();
@@ -601,13 +624,20 @@ int unetk_nhwc_to_nchw(const void* src, int ld, float* dst, int B, int C, int H,
   return UNETK_OK;
 }
 
-int unetk_bn_finalize(const float* partials, int nparts, int C, int64_t count, const float* gamma,
+int unetk_bn_finalize(float* partials, int nparts, int C, int64_t count, const float* gamma,
                       const float* beta, float eps, float momentum, float* running_mean,
                       float* running_var, float* mean, float* invstd, float* scale, float* shift,
                       hipStream_t stream) {
   UNETK_CHECK_ARG(partials && mean && invstd && scale && shift && nparts > 0 && C > 0 && count > 0,
                   "bn_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, partials, nparts, C,
+  int G = 0;
+  if (nparts >= 1024) {   // long lists: a wide first level, in place
+    G = 64;
+    hipLaunchKernelGGL(bn_prereduce_kernel, dim3(cdiv(nparts, G), cdiv(2 * C, 256)), dim3(256), 0, stream,
+                       partials, nparts, 2 * C, G);
+    UNETK_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, partials, nparts, G, C,
                      (double)count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
                      scale, shift);
   UNETK_CHECK_LAUNCH();
