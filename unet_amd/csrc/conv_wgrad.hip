@@ -81,11 +81,19 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
   constexpr int DBUF = DINSTR * 1024, HBUF = HINSTR * 1024;
   constexpr int KSTEP_PIX = BF ? 32 : 4;
   constexpr int NKS = TPIX / KSTEP_PIX;
-  // Two separate LDS objects (not one array indexed by parity): the compiler then knows that the
-  // DMA filling one buffer cannot alias the reads of the other and leaves it in flight during the
-  // multiply instead of waiting for it before the first LDS read.
-  __shared__ __attribute__((aligned(1024))) char buf0[DBUF + HBUF];
-  __shared__ __attribute__((aligned(1024))) char buf1[DBUF + HBUF];
+  // Separate LDS objects per pipeline stage (not one array indexed by a counter): the compiler then
+  // knows that the DMA filling one stage cannot alias the reads of another and leaves it in flight
+  // during the multiply instead of waiting for it before the first LDS read.  Three stages where
+  // they fit (the narrow, bandwidth-bound shapes): two tiles in flight behind the one being used.
+  constexpr int STAGE = DBUF + HBUF;
+  constexpr int S = (3 * STAGE <= 160 * 1024) ? 3 : 2;
+  __shared__ __attribute__((aligned(1024))) char buf0[STAGE];
+  __shared__ __attribute__((aligned(1024))) char buf1[STAGE];
+  __shared__ __attribute__((aligned(1024))) char buf2[S == 3 ? STAGE : 1024];
+  // every wave issues the same number of DMA instructions per tile (the surplus ones repeat the
+  // last piece), so "all but the newest tile" is a fixed vmcnt
+  constexpr int DPW = (DINSTR + 7) / 8, HPW = (HINSTR + 7) / 8, NPW = DPW + HPW;
+  static_assert(2 * NPW < 64, "vmcnt range");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -121,7 +129,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
     const int b = t / a.tiles_y;
     const int y0 = ty * TR, x0 = tx * TW;
     char* hbuf = dbuf + DBUF;
-    for (int i = wave; i < DINSTR; i += 8) {      // dy tile: [pixel][BM channels]
+#pragma unroll
+    for (int k = 0; k < DPW; ++k) {               // dy tile: [pixel][BM channels]
+      int i = wave + 8 * k;
+      if (i >= DINSTR) i = DINSTR - 1;
       const int part = i * 64 + lane;
       const int pix = part / PPD, slot = part - pix * PPD;
       const int tr = pix / TW, tc = pix - tr * TW;
@@ -132,7 +143,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
         src = dy + (((long)b * a.H + gy) * a.W + gx) * a.lddy + c;
       glds16(src, dbuf + i * 1024);
     }
-    for (int i = wave; i < HINSTR; i += 8) {      // input halo: [(TR+2)*(TW+2) pixels][KCI channels]
+#pragma unroll
+    for (int k = 0; k < HPW; ++k) {               // input halo: [(TR+2)*(TW+2) pixels][KCI channels]
+      int i = wave + 8 * k;
+      if (i >= HINSTR) i = HINSTR - 1;
       const int part = i * 64 + lane;
       const int pix = part / PPH, slot = part - pix * PPH;
       const int hy = pix / HW_, hx = pix - hy * HW_;
@@ -219,17 +233,46 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
     }
   };
 
-  // tile k+1 is in flight while tile k is multiplied; one barrier per tile
-  if (bz < a.ntiles) issue_tile(bz, buf0);
+  const int n = bz < a.ntiles ? (a.ntiles - bz + a.nsplit - 1) / a.nsplit : 0;   // tiles of this workgroup
+  auto tile_at = [&](int j) { return bz + j * a.nsplit; };
+  if constexpr (S == 2) {
+    // tile j+1 is in flight while tile j is multiplied; one barrier per tile
+    if (n > 0) issue_tile(tile_at(0), buf0);
 #pragma unroll 1
-  for (int tile = bz; tile < a.ntiles; tile += 2 * a.nsplit) {
-    __syncthreads();     // buf0 has landed for every wave; everyone is done reading buf1
-    if (tile + a.nsplit < a.ntiles) issue_tile(tile + a.nsplit, buf1);
-    multiply(buf0);
-    if (tile + a.nsplit >= a.ntiles) break;
-    __syncthreads();
-    if (tile + 2 * a.nsplit < a.ntiles) issue_tile(tile + 2 * a.nsplit, buf0);
-    multiply(buf1);
+    for (int j = 0; j < n; j += 2) {
+      __syncthreads();     // buf0 has landed for every wave; everyone is done reading buf1
+      if (j + 1 < n) issue_tile(tile_at(j + 1), buf1);
+      multiply(buf0);
+      if (j + 1 >= n) break;
+      __syncthreads();
+      if (j + 2 < n) issue_tile(tile_at(j + 2), buf0);
+      multiply(buf1);
+    }
+  } else {
+    // Tiles j+1 and j+2 are in flight while tile j is multiplied.  Before the barrier a wave waits
+    // for its own pieces of tile j only: vector-memory loads complete in order, so that is "all
+    // but the NPW newest" whenever tile j+1 has been issued.  After the barrier tile j is complete
+    // and every wave is done with tile j-1, whose stage the next issue overwrites.
+    auto sync_tile = [&](bool newer_in_flight) {
+      if (newer_in_flight) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    if (n > 0) issue_tile(tile_at(0), buf0);
+    if (n > 1) issue_tile(tile_at(1), buf1);
+#pragma unroll 1
+    for (int j = 0; j < n; j += 3) {
+      sync_tile(j + 1 < n);
+      if (j + 2 < n) issue_tile(tile_at(j + 2), buf2);
+      multiply(buf0);
+      if (j + 1 >= n) break;
+      sync_tile(j + 2 < n);
+      if (j + 3 < n) issue_tile(tile_at(j + 3), buf0);
+      multiply(buf1);
+      if (j + 2 >= n) break;
+      sync_tile(j + 3 < n);
+      if (j + 4 < n) issue_tile(tile_at(j + 4), buf1);
+      multiply(buf2);
+    }
   }
 
   // slab[(NWK*z + wk)][co][tap][ci]; C layout: col (ci) = lane&15, row (co) = 4*(lane>>4)+r
@@ -285,7 +328,11 @@ WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int dtype) {
   p.mt = (Co % 48 == 0) ? 3 : ((Co % 64 == 0 || Co > 48) ? 4 : (Co > 32 ? 3 : 2));
   p.tw = (W <= 16) ? 16 : 32;
   // 64 input channels per workgroup when that wastes no padding, else 32
-  p.nwn = (dtype == UNETK_BF16 && (Ci % 64 == 0 || (Ci > 256 && (Ci % 64) > 32))) ? 4 : 2;
+  // Low-intensity shapes (flops per operand byte = 9*Co*Ci/(Co+Ci)) are bandwidth-bound: they
+  // also take 64-channel chunks, trading padded MFMA work for fewer passes over dy.
+  const bool low_intensity = 9.0 * Co * Ci / (Co + Ci) < 350.0;
+  p.nwn = (dtype == UNETK_BF16 && (Ci % 64 == 0 || (Ci > 256 && (Ci % 64) > 32) || (low_intensity && Ci > 32)))
+              ? 4 : 2;
   p.nwk = 8 / p.nwn;
   p.tpix = dtype == UNETK_BF16 ? 256 : 128;
   p.tr = p.tpix / p.tw;
