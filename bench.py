@@ -10,9 +10,10 @@ the data-parallel gradient all-reduce over RCCL).  Workload = BASELINE config 2:
 4x256x256 patches per GPU, bf16 storage with fp32 accumulation.  Rank 0 prints ONE JSON line.
 
 The line also carries
-  roofline     - the MFMA implicit-GEMM conv family (forward + data-gradient launches): algorithmic
-                 FLOPs of those launches / their summed duration, measured with events on the
-                 launch stream in an extra instrumented step, against the 2.5 PFLOP/s dense bf16 peak;
+  roofline     - the dominant kernel, the MFMA implicit-GEMM conv with 96-channel blocks (forward and
+                 data-gradient launches): algorithmic FLOPs per launch / average launch duration,
+                 measured with events on the launch stream inside the timed steps, against the
+                 2.5 PFLOP/s dense bf16 peak (plus the same ratio over the whole conv family);
   cpu_baseline - the CPU oracle (torch fp32) timed on this host on a bounded sample of the same
                  workload (batch 4, same network and loss).
 """
@@ -70,36 +71,57 @@ def train_step(model, crit, x, y, w):
     return loss
 
 
-def conv_family_roofline(model, crit, x, y, w, dt):
-    """Instrument every implicit-GEMM conv launch of one step with events on the launch stream."""
-    from unet_amd import ops
-    records = []
-    orig = ops.conv_fwd
+class ConvTimer:
+    """Brackets every implicit-GEMM conv launch (forward and data-gradient) of the timed steps with
+    events on the launch stream.  The roofline entry is the dominant instantiation,
+    conv_igemm_kernel<bf16, NT=6, KS=3> (96-channel blocks, 3x3): 27 of the 36 launches per step."""
 
-    def timed(xin, pw, *a, **k):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        r = orig(xin, pw, *a, **k)
-        e1.record()
-        B, H, W_, _ = xin.shape
-        flops = 2.0 * B * H * W_ * pw.Co * pw.Ci * pw.ks * pw.ks
-        records.append((e0, e1, flops))
-        return r
+    def __init__(self):
+        from unet_amd import ops
+        self.ops = ops
+        self.orig = ops.conv_fwd
+        self.records = []
 
-    ops.conv_fwd = timed
-    try:
-        train_step(model, crit, x, y, w)
-        torch.cuda.synchronize()
-    finally:
-        ops.conv_fwd = orig
-    ms = sum(e0.elapsed_time(e1) for e0, e1, _ in records)
-    flops = sum(f for _, _, f in records)
-    achieved = flops / (ms * 1e-3) / 1e12
-    peak = PEAK_BF16_TFLOPS if dt == torch.bfloat16 else PEAK_F32_TFLOPS
-    return {"bound": "mfma", "kernel": "conv_igemm_kernel (forward + data-gradient launches)",
-            "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-            "traffic": None, "launches": len(records), "ms_per_step_in_kernel": round(ms, 3),
-            "algorithmic_tflop_per_step": round(flops / 1e12, 3)}
+    def __enter__(self):
+        orig, records = self.orig, self.records
+
+        def timed(xin, pw, *a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(xin, pw, *a, **k)
+            e1.record()
+            B, H, W_, _ = xin.shape
+            records.append((e0, e1, 2.0 * B * H * W_ * pw.Co * pw.Ci * pw.ks * pw.ks, pw.bn, pw.ks))
+            return r
+
+        self.ops.conv_fwd = timed
+        return self
+
+    def __exit__(self, *exc):
+        self.ops.conv_fwd = self.orig
+
+    def roofline(self, dt, steps):
+        peak = PEAK_BF16_TFLOPS if dt == torch.bfloat16 else PEAK_F32_TFLOPS
+        dom = [(e0.elapsed_time(e1), f) for e0, e1, f, bn, ks in self.records if bn == 96 and ks == 3]
+        fam = [(e0.elapsed_time(e1), f) for e0, e1, f, bn, ks in self.records]
+        ms, flops = sum(t for t, _ in dom), sum(f for _, f in dom)
+        fms, fflops = sum(t for t, _ in fam), sum(f for _, f in fam)
+        achieved = flops / (ms * 1e-3) / 1e12
+        tname = "bf16" if dt == torch.bfloat16 else "f32"
+        traffic = None
+        try:   # HBM bytes per launch of this kernel from separate rocprofv3 --pmc passes (tools/pmc_traffic.py)
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                traffic = json.load(f).get(f"conv_igemm_kernel<{tname},6,3>", {}).get("hbm_bytes_per_launch")
+        except (OSError, ValueError):
+            pass
+        return {"bound": "mfma", "kernel": f"conv_igemm_kernel<{tname},6,3> (forward + data-gradient launches)",
+                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                "traffic": traffic, "launches_per_step": len(dom) // steps,
+                "avg_launch_us": round(ms * 1e3 / len(dom), 2),
+                "algorithmic_gflop_per_launch": round(flops / len(dom) / 1e9, 2),
+                "conv_family": {"launches_per_step": len(fam) // steps,
+                                "ms_per_step": round(fms / steps, 3),
+                                "achieved": round(fflops / (fms * 1e-3) / 1e12, 2)}}
 
 
 def cpu_baseline(batch, size):
@@ -160,10 +182,15 @@ def main():
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
+    timer = ConvTimer() if (rank == 0 and not args.no_roofline) else None
+    if timer is not None:
+        timer.__enter__()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
+    if timer is not None:
+        timer.__exit__()
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
@@ -178,8 +205,8 @@ def main():
     roof = None
     cpu = None
     if rank == 0:
-        if not args.no_roofline:
-            roof = conv_family_roofline(model, crit, x, y, w, dt)
+        if timer is not None:
+            roof = timer.roofline(dt, args.steps)
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(4, args.size)
         line = {

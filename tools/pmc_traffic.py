@@ -1,0 +1,38 @@
+#!/usr/bin/env python
+"""HBM traffic per launch from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE, separate runs).
+
+    python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>
+
+Both counters are in KiB.  On gfx950 FETCH_SIZE tallies the 128-byte requests of wide coalesced
+reads at 64 bytes, so the read side is doubled; WRITE_SIZE is exact for 16-byte-per-lane stores.
+"""
+import csv, json, sys
+from collections import defaultdict
+sys.path.insert(0, __file__.rsplit("/", 1)[0])
+from prof_summary import short
+
+
+def per_kernel(path, counter):
+    tot, n = defaultdict(float), defaultdict(int)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        k = short(r["Kernel_Name"])
+        tot[k] += float(r["Counter_Value"])
+        n[k] += 1
+    return tot, n
+
+
+fetch, nf = per_kernel(sys.argv[1], "FETCH_SIZE")
+write, nw = per_kernel(sys.argv[2], "WRITE_SIZE")
+out = {}
+for k in sorted(fetch, key=lambda k: -fetch[k]):
+    if nf[k] == 0 or nw.get(k, 0) == 0:
+        continue
+    rd = 2.0 * fetch[k] / nf[k] * 1024
+    wr = write[k] / nw[k] * 1024
+    out[k] = {"launches_sampled": nf[k], "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
+              "hbm_bytes_per_launch": round(rd + wr)}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+for k, v in list(out.items())[:12]:
+    print(k, v)

@@ -13,9 +13,9 @@
 // and the input halo of a tile are brought in by LDS-DMA (global_load_lds) into a double buffer:
 // tile k+1 is in flight while tile k is multiplied, one barrier per tile.  Every tap is a shifted
 // window of the same halo.  Waves split the work as (16-channel slice of the input chunk) x
-// (k-step residue); each k-residue writes its own fp32 partial into a slab
-// [NWK*S][Co_pad][taps][Ci_pad]; a second kernel sums the slabs in a fixed order (bitwise
-// reproducible, no atomics) and writes the [Co][Ci][KS][KS] fp32 gradient.
+// (k-step residue); the residues are summed through LDS at the end and the workgroup writes one
+// fp32 partial into a slab [S][Co_pad][taps][Ci_pad]; a second kernel sums the slabs in a fixed
+// order (bitwise reproducible, no atomics) and writes the [Co][Ci][KS][KS] fp32 gradient.
 #include "common.h"
 
 namespace {
@@ -275,8 +275,36 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
     }
   }
 
-  // slab[(NWK*z + wk)][co][tap][ci]; C layout: col (ci) = lane&15, row (co) = 4*(lane>>4)+r
-  float* slab = a.slab + (long)(NWK * bz + wk) * a.Co_pad * TAPS * a.Ci_pad;
+  // Sum the k-residues of the workgroup through LDS (fixed order: residue w + half into w, halving),
+  // one 16-channel row block at a time so the exchange area is 4 waves x 9 KiB at most.
+  static_assert(4 * TAPS * 4 * 64 * 4 <= STAGE, "exchange area");
+  float* xch = reinterpret_cast<float*>(buf0);
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+#pragma unroll
+    for (int half = NWK / 2; half >= 1; half >>= 1) {
+      __syncthreads();   // (first trip: every wave is done with the last tile)
+      if (wk >= half && wk < 2 * half) {
+        float* dst = xch + ((wk - half) * NWN + wn) * (TAPS * 4 * 64) + lane;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dst[(t * 4 + r) * 64] = acc[m][t][r];
+      }
+      __syncthreads();
+      if (wk < half) {
+        const float* src = xch + (wk * NWN + wn) * (TAPS * 4 * 64) + lane;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[m][t][r] += src[(t * 4 + r) * 64];
+      }
+    }
+  }
+  if (wk != 0) return;
+
+  // slab[z][co][tap][ci]; C layout: col (ci) = lane&15, row (co) = 4*(lane>>4)+r
+  float* slab = a.slab + (long)bz * a.Co_pad * TAPS * a.Ci_pad;
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -344,7 +372,7 @@ WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int dtype) {
   p.Ci_pad = cdiv(Ci, kci) * kci;
   const int gxy = (p.Ci_pad / kci) * (p.Co_pad / (p.mt * 16));
   int s = 768 / gxy;                       // one workgroup per CU: aim at ~3 rounds of 256
-  if (s * p.nwk > 512) s = 512 / p.nwk;    // bound the number of partial slabs
+  if (s > 256) s = 256;                    // bound the number of partial slabs
   if (s < 1) s = 1;
   if (s > p.ntiles) s = p.ntiles;
   if (s >= 32) s &= ~7;                    // multiples of 8 enable the XCD-aware workgroup order
@@ -376,7 +404,7 @@ extern "C" {
 
 int64_t unetk_conv_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Co, int ks, int dtype) {
   const WgradPlan p = plan_wgrad(B, H, W, Ci, Co, dtype);
-  return (int64_t)p.nwk * p.nsplit * p.Co_pad * ks * ks * p.Ci_pad * 4;
+  return (int64_t)p.nsplit * p.Co_pad * ks * ks * p.Ci_pad * 4;
 }
 
 int unetk_conv_wgrad(const void* in, int ldin, const void* dy, int lddy, float* dw, int B, int H, int W,
@@ -406,7 +434,7 @@ int unetk_conv_wgrad(const void* in, int ldin, const void* dy, int lddy, float* 
   if (rc != UNETK_OK) return rc;
   const long nblocks = (long)Co * ks * ks * (p.Ci_pad / 32);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)nblocks), dim3(256), 0, stream, a.slab, dw,
-                     p.nwk * p.nsplit, Co, Ci, p.Co_pad, p.Ci_pad, ks * ks, accumulate);
+                     p.nsplit, Co, Ci, p.Co_pad, p.Ci_pad, ks * ks, accumulate);
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }

@@ -285,23 +285,32 @@ __global__ __launch_bounds__(LT) void spectral_fwd_kernel(const float2* __restri
 }
 
 // spectral = 0.01 * mean_b [ (sum_b / HW) * wbar_b / HW ];  coef[b] = 0.01/B * wbar_b / HW^2
-__global__ void spectral_finalize_kernel(const float* __restrict__ partials, const float* __restrict__ wsum,
-                                         int nblk, int B, int H, int W, int has_w, float* __restrict__ res,
-                                         float* __restrict__ coef) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(256) void spectral_finalize_kernel(const float* __restrict__ partials,
+                                                                const float* __restrict__ wsum, int nblk, int B,
+                                                                int H, int W, int has_w, float* __restrict__ res,
+                                                                float* __restrict__ coef) {
+  // one thread per sample sums that sample's partials in order; thread 0 then adds the samples in order
+  __shared__ double term[256];
   const double hw = (double)H * W;
   double total = 0.0;
-  for (int b = 0; b < B; ++b) {
-    double s = 0.0, ws = 0.0;
-    for (int i = 0; i < nblk; ++i) {
-      s += (double)partials[b * nblk + i];
-      ws += (double)wsum[b * nblk + i];
+  for (int b0 = 0; b0 < B; b0 += 256) {
+    const int b = b0 + threadIdx.x;
+    if (b < B) {
+      double s = 0.0, ws = 0.0;
+      for (int i = 0; i < nblk; ++i) {
+        s += (double)partials[b * nblk + i];
+        ws += (double)wsum[b * nblk + i];
+      }
+      const double wbar = has_w ? ws / hw : 1.0;
+      term[threadIdx.x] = (s / hw) * wbar / hw;
+      coef[b] = (float)(0.01 / B * wbar / (hw * hw));
     }
-    const double wbar = has_w ? ws / hw : 1.0;
-    total += (s / hw) * wbar / hw;
-    coef[b] = (float)(0.01 / B * wbar / (hw * hw));
+    __syncthreads();
+    if (threadIdx.x == 0)
+      for (int k = 0; k < 256 && b0 + k < B; ++k) total += term[k];
+    __syncthreads();
   }
-  res[2] = (float)(0.01 * total / B);
+  if (threadIdx.x == 0) res[2] = (float)(0.01 * total / B);
 }
 
 // Z[k] = gscale * coef[b] * 2*(lp-lt)*fw / (|Fp|+eps) * conj(Fp)/|Fp|   (0 where |Fp| == 0)
@@ -377,7 +386,7 @@ int unetk_loss_spectral_fwd(const void* Fp, const void* Ft, const float* w, int 
   hipLaunchKernelGGL(spectral_fwd_kernel, dim3(nblk, B), dim3(LT), 0, stream, (const float2*)Fp,
                      (const float2*)Ft, w, H, W, factor, partials, wsum);
   UNETK_CHECK_LAUNCH();
-  hipLaunchKernelGGL(spectral_finalize_kernel, dim3(1), dim3(64), 0, stream, partials, wsum, nblk, B, H, W,
+  hipLaunchKernelGGL(spectral_finalize_kernel, dim3(1), dim3(256), 0, stream, partials, wsum, nblk, B, H, W,
                      w != nullptr, res, coef);
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;

@@ -220,7 +220,42 @@ __global__ __launch_bounds__(RED_THREADS) void channel_reduce_kernel(RedArgs a) 
     long pend = pbeg + a.chunk;
     if (pend > a.npix) pend = a.npix;
     const T* x = reinterpret_cast<const T*>(a.x);
-    for (long p = pbeg + pl; p < pend; p += lanes) {
+    // four pixels per trip: all eight loads are issued before the first is consumed
+    constexpr int U = 4;
+    long p = pbeg + pl;
+    for (; p + (U - 1) * lanes < pend; p += U * lanes) {
+      Vec16<T> xv[U], gv[U];
+      float dsc[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long pu = p + u * lanes;
+        xv[u] = load16(x + pu * a.ldx + c0);
+        if (MODE == 0) gv[u] = load16(reinterpret_cast<const T*>(a.g) + pu * a.ldg + c0);
+        else dsc[u] = reinterpret_cast<const float*>(a.g)[pu];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (MODE == 0) {
+          const int b = (p + u * lanes) / a.hw;
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            const float yv = to_f32(xv[u].v[e]);
+            float dz = to_f32(gv[u].v[e]);
+            if (a.keep) dz *= a.keep[(long)b * a.C + c0 + e];
+            if (a.relu && !(yv * sc[e] + sh[e] > 0.f)) dz = 0.f;
+            s0[e] += dz;
+            s1[e] += dz * ((yv - mu[e]) * is[e]);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            s0[e] += dsc[u] * to_f32(xv[u].v[e]);
+            s1[e] += dsc[u];
+          }
+        }
+      }
+    }
+    for (; p < pend; p += lanes) {
       Vec16<T> xv = load16(x + p * a.ldx + c0);
       if (MODE == 0) {
         Vec16<T> gv = load16(reinterpret_cast<const T*>(a.g) + p * a.ldg + c0);
@@ -427,6 +462,12 @@ __global__ void pool_bwd_kernel(const T* __restrict__ a, const T* __restrict__ d
   }
 }
 
+// Block index for a grid of 8*k workgroups in which XCD x (= blockIdx.x % 8) owns blocks [x*k, (x+1)*k).
+__device__ __forceinline__ long xcd_contiguous_block() {
+  const long per = gridDim.x >> 3;
+  return (long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+}
+
 // ------------------------------------------------------------------ bilinear resize (align_corners=False)
 __device__ __forceinline__ void src_index(float scale, int dst, int in_size, int& i0, int& i1, float& l1) {
   float s = scale * ((float)dst + 0.5f) - 0.5f;
@@ -480,7 +521,9 @@ __global__ void upsample_bwd_kernel(const T* __restrict__ dout, int ldout, int H
                                     int B, int h, int w, int C1, float sy, float sx) {
   constexpr int E = Vec16<T>::N;
   const int CG = C1 / E;
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  // Neighbouring low-resolution rows gather from overlapping rows of dout: each XCD (workgroups
+  // are dealt to them round-robin) takes a contiguous range of blocks so the overlap stays in its L2.
+  const long idx = xcd_contiguous_block() * blockDim.x + threadIdx.x;
   if (idx >= (long)B * h * w * CG) return;
   const int cg = idx % CG;
   long p = idx / CG;
@@ -757,7 +800,7 @@ int unetk_upsample_bwd(const void* dout, int ldout, int H, int W, void* dlow, in
   UNETK_CHECK_ARG(ldout % E == 0, "upsample_bwd: stride misaligned");
   const float sy = (float)h / (float)H, sx = (float)w / (float)W;
   const long total = (long)B * h * w * (C1 / E);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(upsample_bwd_kernel<T>, dim3(cdiv(total, 256)), dim3(256), 0, stream,
+  DISPATCH_T(dtype, hipLaunchKernelGGL(upsample_bwd_kernel<T>, dim3(8 * cdiv(cdiv(total, 256), 8)), dim3(256), 0, stream,
                                        (const T*)dout, ldout, H, W, (T*)dlow, B, h, w, C1, sy, sx));
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
