@@ -55,6 +55,13 @@ int unetk_conv_fwd(const void* in, int ldin, const void* wpacked, void* out, int
                    int W, int Ci, int Co, int ks, int bn, int dtype, float* stats,
                    const float* ep_scale, const float* ep_shift, int act, const void* resid, int ldres,
                    const float* resid_keep, unetk_stream_t stream);
+/* Same, with the output channels [split, Co) written to a second tensor out2 (row stride ldout2,
+ * channels renumbered from 0); split must be a multiple of bn.  The data gradient of a conv whose
+ * input was torch.cat([up, skip], dim=1) (training.py:492-505) comes out as the two gradients. */
+int unetk_conv_fwd_split(const void* in, int ldin, const void* wpacked, void* out, int ldout, void* out2,
+                         int ldout2, int split, int B, int H, int W, int Ci, int Co, int ks, int bn,
+                         int dtype, float* stats, const float* ep_scale, const float* ep_shift, int act,
+                         const void* resid, int ldres, const float* resid_keep, unetk_stream_t stream);
 /* dw[Co][Ci][k][k] (+)= sum_pixels dy (x) shifted in   (autograd of the convolutions above) */
 int64_t unetk_conv_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Co, int ks, int dtype);
 int unetk_conv_wgrad(const void* in, int ldin, const void* dy, int lddy, float* dw, int B, int H, int W,

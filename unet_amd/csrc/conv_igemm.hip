@@ -42,9 +42,10 @@ struct ConvArgs {
   float* stats;            // [tiles][2][Co] or null
   const float* ep_scale;   // [Co] or null (=1)
   const float* ep_shift;   // [Co] or null (=0)
+  void* out2;              // output channels >= split go here (ld = ldout2), renumbered from 0; or null
   const void* resid;       // residual (same layout as out, ld = ldres) or null
   const float* resid_keep; // per-sample scale applied to the conv result before the add, or null
-  int ldin, ldout, ldres;
+  int ldin, ldout, ldres, ldout2, split;
   int B, H, W, Ci, Co;
   int nchunks;
   int act;                 // 0 none, 1 relu, 2 gelu(erf)
@@ -304,7 +305,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
           for (int e = 0; e < EPP; ++e)
             v.v[e] = from_f32<T>(to_f32(rv.v[e]) + keep * to_f32(v.v[e]));
         }
-        store16(out + p * a.ldout + c, v);
+        if (a.out2 != nullptr && n0 >= a.split)
+          store16(reinterpret_cast<T*>(a.out2) + p * a.ldout2 + (c - a.split), v);
+        else
+          store16(out + p * a.ldout + c, v);
       }
     }
   }
@@ -424,10 +428,10 @@ int unetk_conv_num_tiles(int B, int H, int W, int ks) {
   return cdiv((long)B * H * W, 256);
 }
 
-int unetk_conv_fwd(const void* in, int ldin, const void* wpacked, void* out, int ldout, int B, int H,
-                   int W, int Ci, int Co, int ks, int bn, int dtype, float* stats,
-                   const float* ep_scale, const float* ep_shift, int act, const void* resid, int ldres,
-                   const float* resid_keep, hipStream_t stream) {
+int unetk_conv_fwd_split(const void* in, int ldin, const void* wpacked, void* out, int ldout, void* out2,
+                         int ldout2, int split, int B, int H, int W, int Ci, int Co, int ks, int bn, int dtype,
+                         float* stats, const float* ep_scale, const float* ep_shift, int act,
+                         const void* resid, int ldres, const float* resid_keep, hipStream_t stream) {
   UNETK_CHECK_ARG(in && wpacked && out, "conv_fwd: null pointer");
   UNETK_CHECK_ARG(ks == 1 || ks == 3, "conv_fwd: kernel size %d (1 or 3)", ks);
   UNETK_CHECK_ARG(dtype == UNETK_F32 || dtype == UNETK_BF16, "conv_fwd: bad dtype %d", dtype);
@@ -436,13 +440,22 @@ int unetk_conv_fwd(const void* in, int ldin, const void* wpacked, void* out, int
   UNETK_CHECK_ARG(Ci % epp == 0 && Co % epp == 0 && ldin % epp == 0 && ldout % epp == 0,
                   "conv_fwd: channels and strides must be multiples of %d (Ci=%d Co=%d ldin=%d ldout=%d)",
                   epp, Ci, Co, ldin, ldout);
-  UNETK_CHECK_ARG(ldin >= Ci && ldout >= Co, "conv_fwd: stride smaller than channel count");
+  if (out2 != nullptr) {
+    UNETK_CHECK_ARG(split > 0 && split < Co && split % bn == 0, "conv_fwd: split %d must be a multiple of the channel block %d inside (0, Co)", split, bn);
+    UNETK_CHECK_ARG(ldout2 % epp == 0 && ldout2 >= Co - split && ldout >= split && ((uintptr_t)out2 % 16) == 0,
+                    "conv_fwd: second output misaligned or too narrow");
+    UNETK_CHECK_ARG(resid == nullptr, "conv_fwd: residual and split output are exclusive");
+  } else {
+    UNETK_CHECK_ARG(ldout >= Co, "conv_fwd: stride smaller than channel count");
+  }
+  UNETK_CHECK_ARG(ldin >= Ci, "conv_fwd: stride smaller than channel count");
   UNETK_CHECK_ARG(((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)wpacked % 16) == 0,
                   "conv_fwd: pointers must be 16-byte aligned");
   UNETK_CHECK_ARG(resid == nullptr || (ldres % epp == 0 && ((uintptr_t)resid % 16) == 0),
                   "conv_fwd: residual misaligned");
   ConvArgs a;
   a.in = in; a.w = wpacked; a.out = out; a.stats = stats;
+  a.out2 = out2; a.ldout2 = ldout2; a.split = out2 ? split : 0;
   a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.resid = resid; a.resid_keep = resid_keep;
   a.ldin = ldin; a.ldout = ldout; a.ldres = ldres;
   a.B = B; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
@@ -452,6 +465,15 @@ int unetk_conv_fwd(const void* in, int ldin, const void* wpacked, void* out, int
   if (dtype == UNETK_BF16)
     return ks == 3 ? launch_conv<bf16, 3>(a, bn, stream) : launch_conv<bf16, 1>(a, bn, stream);
   return ks == 3 ? launch_conv<float, 3>(a, bn, stream) : launch_conv<float, 1>(a, bn, stream);
+}
+
+
+int unetk_conv_fwd(const void* in, int ldin, const void* wpacked, void* out, int ldout, int B, int H,
+                   int W, int Ci, int Co, int ks, int bn, int dtype, float* stats,
+                   const float* ep_scale, const float* ep_shift, int act, const void* resid, int ldres,
+                   const float* resid_keep, hipStream_t stream) {
+  return unetk_conv_fwd_split(in, ldin, wpacked, out, ldout, nullptr, 0, 0, B, H, W, Ci, Co, ks, bn, dtype, stats,
+                              ep_scale, ep_shift, act, resid, ldres, resid_keep, stream);
 }
 
 }  // extern "C"

@@ -220,56 +220,41 @@ __global__ __launch_bounds__(RED_THREADS) void channel_reduce_kernel(RedArgs a) 
     long pend = pbeg + a.chunk;
     if (pend > a.npix) pend = a.npix;
     const T* x = reinterpret_cast<const T*>(a.x);
-    // four pixels per trip: all eight loads are issued before the first is consumed
-    constexpr int U = 4;
-    long p = pbeg + pl;
-    for (; p + (U - 1) * lanes < pend; p += U * lanes) {
-      Vec16<T> xv[U], gv[U];
-      float dsc[U];
+    if (MODE == 0) {
+      // walk the chunk sample by sample: the Dropout2d keep factors are loaded once per sample and
+      // no per-pixel division is needed
+      const T* gp = reinterpret_cast<const T*>(a.g);
+      long seg = pbeg;
+      while (seg < pend) {
+        const long b = seg / a.hw;
+        long seg_end = (b + 1) * a.hw;
+        if (seg_end > pend) seg_end = pend;
+        float kp[E];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const long pu = p + u * lanes;
-        xv[u] = load16(x + pu * a.ldx + c0);
-        if (MODE == 0) gv[u] = load16(reinterpret_cast<const T*>(a.g) + pu * a.ldg + c0);
-        else dsc[u] = reinterpret_cast<const float*>(a.g)[pu];
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (MODE == 0) {
-          const int b = (p + u * lanes) / a.hw;
+        for (int e = 0; e < E; ++e) kp[e] = a.keep ? a.keep[b * a.C + c0 + e] : 1.f;
+        auto one = [&](const Vec16<T>& xv, const Vec16<T>& gv) {
 #pragma unroll
           for (int e = 0; e < E; ++e) {
-            const float yv = to_f32(xv[u].v[e]);
-            float dz = to_f32(gv[u].v[e]);
-            if (a.keep) dz *= a.keep[(long)b * a.C + c0 + e];
+            const float yv = to_f32(xv.v[e]);
+            float dz = to_f32(gv.v[e]) * kp[e];
             if (a.relu && !(yv * sc[e] + sh[e] > 0.f)) dz = 0.f;
             s0[e] += dz;
             s1[e] += dz * ((yv - mu[e]) * is[e]);
           }
-        } else {
-#pragma unroll
-          for (int e = 0; e < E; ++e) {
-            s0[e] += dsc[u] * to_f32(xv[u].v[e]);
-            s1[e] += dsc[u];
-          }
+        };
+        long p = seg + pl;
+        for (; p + lanes < seg_end; p += 2 * lanes) {   // two pixels in flight
+          const Vec16<T> x0 = load16(x + p * a.ldx + c0), g0 = load16(gp + p * a.ldg + c0);
+          const Vec16<T> x1 = load16(x + (p + lanes) * a.ldx + c0), g1 = load16(gp + (p + lanes) * a.ldg + c0);
+          one(x0, g0);
+          one(x1, g1);
         }
+        if (p < seg_end) one(load16(x + p * a.ldx + c0), load16(gp + p * a.ldg + c0));
+        seg = seg_end;
       }
-    }
-    for (; p < pend; p += lanes) {
-      Vec16<T> xv = load16(x + p * a.ldx + c0);
-      if (MODE == 0) {
-        Vec16<T> gv = load16(reinterpret_cast<const T*>(a.g) + p * a.ldg + c0);
-        const int b = p / a.hw;
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-          const float yv = to_f32(xv.v[e]);
-          float dz = to_f32(gv.v[e]);
-          if (a.keep) dz *= a.keep[(long)b * a.C + c0 + e];
-          if (a.relu && !(yv * sc[e] + sh[e] > 0.f)) dz = 0.f;
-          s0[e] += dz;
-          s1[e] += dz * ((yv - mu[e]) * is[e]);
-        }
-      } else {
+    } else {
+      for (long p = pbeg + pl; p < pend; p += lanes) {
+        Vec16<T> xv = load16(x + p * a.ldx + c0);
         const float d = reinterpret_cast<const float*>(a.g)[p];
 #pragma unroll
         for (int e = 0; e < E; ++e) {

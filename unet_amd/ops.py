@@ -72,9 +72,11 @@ class PackedConv:
 
 def conv_fwd(x: torch.Tensor, pw: PackedConv, Ci: Optional[int] = None, Co: Optional[int] = None,
              out: Optional[torch.Tensor] = None, want_stats: bool = False, scale=None, shift=None,
-             act: int = 0, resid=None, resid_keep=None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+             act: int = 0, resid=None, resid_keep=None, split: int = 0):
     """x: (B,H,W,ld) NHWC.  Channel counts default to the packed weight's, rounded up to the
-    vector width for the output (padding channels come out as exact zeros)."""
+    vector width for the output (padding channels come out as exact zeros).  With ``split`` (a
+    multiple of the packed channel block) the result is two tensors, channels [0,split) and
+    [split,Co), and the return value is ((out_a, out_b), stats)."""
     B, H, W, _ = x.shape
     ldin = x.stride(2)
     dt = x.dtype
@@ -82,6 +84,13 @@ def conv_fwd(x: torch.Tensor, pw: PackedConv, Ci: Optional[int] = None, Co: Opti
     Ci = Ci if Ci is not None else min(x.shape[-1], pad_channels(pw.Ci, dt))
     if Co is None:
         Co = out.shape[-1] if out is not None else pad_channels(pw.Co, dt)
+    if split:
+        out = torch.empty((B, H, W, split), dtype=dt, device=x.device)
+        out2 = torch.empty((B, H, W, Co - split), dtype=dt, device=x.device)
+        call("unetk_conv_fwd_split", ptr(x), ldin, ptr(pw.data), ptr(out), split, ptr(out2), Co - split, split,
+             B, H, W, Ci, Co, pw.ks, pw.bn, dtype_code(dt), None, ptr(scale), ptr(shift), act, None, 0, None,
+             stream())
+        return (out, out2), None
     if out is None:
         out = torch.empty((B, H, W, Co), dtype=dt, device=x.device)
     ldout = out.stride(2)          # `out` may be a channel slice of a wider (concat) buffer
@@ -197,8 +206,9 @@ def upsample_concat(low, skip):
 
 
 def upsample_bwd(dcat, C1, h, w):
-    """Gradient of the resized half of a concat buffer (B,H,W,C1+C2) -> (B,h,w,C1)."""
-    B, H, W, ld = dcat.shape
+    """Gradient of the resized channels [0,C1) of dcat (B,H,W,>=C1; may be a channel slice) -> (B,h,w,C1)."""
+    B, H, W, _ = dcat.shape
+    ld = dcat.stride(2)
     dlow = torch.empty((B, h, w, C1), dtype=dcat.dtype, device=dcat.device)
     call("unetk_upsample_bwd", ptr(dcat), ld, H, W, ptr(dlow), B, h, w, C1, dtype_code(dcat.dtype), stream())
     return dlow

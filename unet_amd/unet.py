@@ -234,7 +234,7 @@ class _UNetTrainFn(torch.autograd.Function):
         g, dw, db = ops.head1x1_bwd(a_d1, model.conv.weight, dout)
         grads["conv.weight"], grads["conv.bias"] = dw, db
 
-        def block_bwd(name, g, need_dx=True):
+        def block_bwd(name, g, need_dx=True, split=0):
             seq = getattr(model, name)
             units, a_out, keep = saved[name]
             for u in (1, 0):
@@ -256,26 +256,28 @@ class _UNetTrainFn(torch.autograd.Function):
                     dw.record_stream(main)
                 grads[f"{name}.{ci}.weight"] = dw
                 if u == 1 or need_dx:
-                    g, _ = ops.conv_fwd(dy, pkT[(name, ci)])
+                    pw = pkT[(name, ci)]
+                    # the first conv of a decoder block read cat([up, skip]): its data gradient comes
+                    # out as two dense tensors (when the boundary falls on a channel block)
+                    sp = split if (u == 0 and split and split % pw.bn == 0) else 0
+                    g, _ = ops.conv_fwd(dy, pw, split=sp)
+                    if u == 0 and split and not sp:
+                        g = (g[..., :split], g[..., split:])
                 else:
                     g = None
             return g
 
-        g = block_bwd("decoder1", g)
         enc_names = ("encoder1", "encoder2", "encoder3", "encoder4")
         dskips = {}
         for name, enc in (("decoder1", "encoder1"), ("decoder2", "encoder2"), ("decoder3", "encoder3"),
                           ("decoder4", "encoder4")):
-            if name != "decoder1":
-                g = block_bwd(name, g)
             (lh, lw), C1 = saved[name + ".low"]
-            dskips[enc] = (g, C1)          # skip gradient = channels [C1:] of the concat gradient
-            g = ops.upsample_bwd(g, C1, lh, lw)
+            g_up, dskips[enc] = block_bwd(name, g, split=C1)
+            g = ops.upsample_bwd(g_up, C1, lh, lw)
         g = block_bwd("bottleneck", g)
         for enc in reversed(enc_names):
             _, a_enc, _ = saved[enc]
-            dcat, C1 = dskips[enc]
-            g = ops.pool_bwd(a_enc, g, dcat[..., C1:])
+            g = ops.pool_bwd(a_enc, g, dskips[enc])
             g = block_bwd(enc, g, need_dx=(enc != "encoder1") or ctx.need_dx)
         dx = None
         if ctx.need_dx:
