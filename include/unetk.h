@@ -85,9 +85,13 @@ int unetk_bn_fold_eval(const float* gamma, const float* beta, const float* runni
                        const float* running_var, float eps, const float* conv_bias, float* scale,
                        float* shift, int C, unetk_stream_t stream);
 /* a = relu(y*scale+shift) * keep[b][c]; pooled (nullable) = 2x2 max of a.
- * scale/shift null = identity, a null = only the pooled output is written (plain MaxPool2d). */
-int unetk_bn_act_fwd(const void* y, void* a, void* pooled, int B, int H, int W, int C, const float* scale,
-                     const float* shift, const float* keep, int relu, int dtype, unetk_stream_t stream);
+ * scale/shift null = identity, a null = only the pooled output is written (plain MaxPool2d).
+ * a has row stride lda (it may be the skip slice of the decoder's concat buffer, which saves the
+ * torch.cat copy of training.py:505).  argmax (nullable, [B][H/2][W/2][C] bytes) receives the
+ * position 0..3 of the first maximum of each quad, for unetk_pool_bwd. */
+int unetk_bn_act_fwd(const void* y, void* a, int lda, void* pooled, unsigned char* argmax, int B, int H,
+                     int W, int C, const float* scale, const float* shift, const float* keep, int relu,
+                     int dtype, unetk_stream_t stream);
 int unetk_reduce_num_partials(int64_t npix);
 /* dy = BN'(relu'(keep * g)); dgamma/dbeta (nullable) (+)=.
  * scratch owned by the caller: partials [num_partials][2][C] floats, sums [6][C] floats */
@@ -95,12 +99,14 @@ int unetk_bn_act_bwd(const void* g, const void* y, void* dy, int B, int H, int W
                      const float* scale, const float* shift, const float* mean, const float* invstd,
                      const float* keep, int relu, float* dgamma, float* dbeta, int accumulate,
                      float* partials, float* sums, int dtype, unetk_stream_t stream);
-/* da = dskip + route(dpooled to the first maximum of each 2x2 quad of a) */
-int unetk_pool_bwd(const void* a, const void* dpooled, const void* dskip, int ldskip, void* da, int B,
-                   int H, int W, int C, int dtype, unetk_stream_t stream);
+/* da = dskip + route(dpooled to the first maximum of each 2x2 quad): the maximum is taken from
+ * argmax when given (a may then be null), else recomputed from a. */
+int unetk_pool_bwd(const void* a, const unsigned char* argmax, const void* dpooled, const void* dskip,
+                   int ldskip, void* da, int B, int H, int W, int C, int dtype, unetk_stream_t stream);
 
 /* ---- F.interpolate(bilinear, align_corners=False) to the skip's size + torch.cat -----
- * training.py:504-517 */
+ * training.py:504-517.  out has C1+C2 channels per pixel; with skip == NULL only the resized
+ * channels [0,C1) are written (the skip half was put there by unetk_bn_act_fwd). */
 int unetk_upsample_concat_fwd(const void* low, int h, int w, int C1, const void* skip, int ldskip, int C2,
                               void* out, int B, int H, int W, int dtype, unetk_stream_t stream);
 int unetk_upsample_bwd(const void* dout, int ldout, int H, int W, void* dlow, int B, int h, int w, int C1,

@@ -158,6 +158,12 @@ def test_pool_bwd_first_max_and_skip(dt, shape):
     skip = rnd((B, C + 8, H, W), 12, dt)            # skip gradient lives in channels [8:] of a wider buffer
     sk = nhwc(skip, dt)
     da = ops.pool_bwd(nhwc(a, dt), nhwc(gp, dt), sk[..., 8:])
+    # the same through the forward's argmax map, the activation written into a channel slice
+    wide = torch.zeros((B, H, W, C + 8), dtype=dt, device="cuda")
+    a2, pooled2, amap = ops.bn_act_fwd(nhwc(a, dt), None, None, None, relu=False, pool=True, out=wide[..., 8:],
+                                       want_argmax=True)
+    assert torch.equal(wide[..., 8:], nhwc(a, dt)) and torch.equal(wide[..., :8], torch.zeros_like(wide[..., :8]))
+    assert torch.equal(ops.pool_bwd(None, nhwc(gp, dt), sk[..., 8:], argmax=amap), da)
     want = ar.grad + skip[:, 8:]
     assert rel(nchw(da), want) < TOL[dt]
 

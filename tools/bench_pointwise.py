@@ -34,11 +34,12 @@ for hw, C in levels:
     res["bn_act_bwd"] = (timeit(lambda: ops.bn_act_bwd(g, y, sc, sh, mean, invstd, keep, relu=True)), 5 * S)
     a, pooled = ops.bn_act_fwd(y, sc, sh, keep, relu=True, pool=True)
     dp = torch.randn_like(pooled)
-    dcat = torch.randn(B, hw, hw, 3 * C, device="cuda").to(dt)
-    res["pool_bwd"] = (timeit(lambda: ops.pool_bwd(a, dp, dcat[..., 2 * C:])), 3.25 * S)
+    dskip = torch.randn(B, hw, hw, C, device="cuda").to(dt)
+    dup = torch.randn(B, hw, hw, 2 * C, device="cuda").to(dt)
+    res["pool_bwd"] = (timeit(lambda: ops.pool_bwd(a, dp, dskip)), 3.25 * S)
     low = torch.randn(B, hw // 2, hw // 2, 2 * C, device="cuda").to(dt)
     res["upsample_concat"] = (timeit(lambda: ops.upsample_concat(low, a)), (0.5 + 1 + 3) * S)
-    res["upsample_bwd"] = (timeit(lambda: ops.upsample_bwd(dcat, 2 * C, hw // 2, hw // 2)), 2.5 * S)
+    res["upsample_bwd"] = (timeit(lambda: ops.upsample_bwd(dup, 2 * C, hw // 2, hw // 2)), 2.5 * S)
     line = f"{hw:4d}^2 C={C:4d} S={S*1e3:6.0f} MB |"
     for k, (t, gb) in res.items():
         line += f" {k} {t*1e3:6.0f} us {gb/t:5.2f} TB/s |"

@@ -119,12 +119,14 @@ __global__ void bn_fold_eval_kernel(const float* gamma, const float* beta, const
 }
 
 // ------------------------------------------------------------------ BN + ReLU (+mask)(+pool) forward
-// One thread per (2x2 pixel quad, 16-byte channel group).
+// One thread per (2x2 pixel quad, 16-byte channel group).  `a` may be a channel slice of a wider
+// buffer (row stride lda); argmax (nullable) receives, per pooled element, the position 0..3
+// (row-major in the quad) of its first maximum, which is all the pooling backward needs.
 template <typename T>
-__global__ void bn_act_fwd_kernel(const T* __restrict__ y, T* __restrict__ a, T* __restrict__ pooled, int B,
-                                  int H, int W, int C, const float* __restrict__ scale,
-                                  const float* __restrict__ shift, const float* __restrict__ keep,
-                                  int relu) {
+__global__ void bn_act_fwd_kernel(const T* __restrict__ y, T* __restrict__ a, int lda, T* __restrict__ pooled,
+                                  unsigned char* __restrict__ argmax, int B, int H, int W, int C,
+                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                  const float* __restrict__ keep, int relu) {
   constexpr int E = Vec16<T>::N;
   const int CG = C / E;
   const int QH = (H + 1) >> 1, QW = (W + 1) >> 1;
@@ -146,16 +148,20 @@ __global__ void bn_act_fwd_kernel(const T* __restrict__ y, T* __restrict__ a, T*
     kp[e] = keep ? keep[(long)b * C + c0 + e] : 1.f;
   }
   float mx[E];
+  unsigned char arg[E];
 #pragma unroll
-  for (int e = 0; e < E; ++e) mx[e] = -INFINITY;
+  for (int e = 0; e < E; ++e) {
+    mx[e] = -INFINITY;
+    arg[e] = 0;
+  }
 #pragma unroll
   for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
     for (int dx = 0; dx < 2; ++dx) {
       const int yy = 2 * qy + dy, xx = 2 * qx + dx;
       if (yy < H && xx < W) {
-        const long off = (((long)b * H + yy) * W + xx) * C + c0;
-        Vec16<T> v = load16(y + off);
+        const long pix = ((long)b * H + yy) * W + xx;
+        Vec16<T> v = load16(y + pix * C + c0);
         Vec16<T> o;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -163,16 +169,27 @@ __global__ void bn_act_fwd_kernel(const T* __restrict__ y, T* __restrict__ a, T*
           if (relu) z = fmaxf(z, 0.f);
           z *= kp[e];
           o.v[e] = from_f32<T>(z);
-          mx[e] = fmaxf(mx[e], to_f32(o.v[e]));
+          const float zr = to_f32(o.v[e]);
+          if (zr > mx[e] || (dy == 0 && dx == 0)) {   // strict '>': the first maximum in scan order
+            mx[e] = zr;
+            arg[e] = (unsigned char)(2 * dy + dx);
+          }
         }
-        if (a != nullptr) store16(a + off, o);
+        if (a != nullptr) store16(a + pix * lda + c0, o);
       }
     }
   if (pooled != nullptr && 2 * qy + 1 < H && 2 * qx + 1 < W) {
     Vec16<T> o;
 #pragma unroll
     for (int e = 0; e < E; ++e) o.v[e] = from_f32<T>(mx[e]);
-    store16(pooled + (((long)b * (H >> 1) + qy) * (W >> 1) + qx) * C + c0, o);
+    const long q = (((long)b * (H >> 1) + qy) * (W >> 1) + qx) * C + c0;
+    store16(pooled + q, o);
+    if (argmax != nullptr) {
+#pragma unroll
+      for (int e = 0; e < E; e += 4)
+        *reinterpret_cast<unsigned int*>(argmax + q + e) =
+            arg[e] | (arg[e + 1] << 8) | (arg[e + 2] << 16) | ((unsigned)arg[e + 3] << 24);
+    }
   }
 }
 
@@ -384,10 +401,11 @@ __global__ __launch_bounds__(RED_THREADS) void bn_act_bwd_apply_kernel(
 
 // ------------------------------------------------------------------ 2x2 max-pool backward (+ skip grad)
 // da[pix] = dskip[pix] + (pix is the first maximum of its quad ? dpooled[quad] : 0)
+// The first maximum comes from the forward's argmax map when given, else it is recomputed from a.
 template <typename T>
-__global__ void pool_bwd_kernel(const T* __restrict__ a, const T* __restrict__ dpooled,
-                                const T* __restrict__ dskip, int ldskip, T* __restrict__ da, int B, int H,
-                                int W, int C) {
+__global__ void pool_bwd_kernel(const T* __restrict__ a, const unsigned char* __restrict__ argmax,
+                                const T* __restrict__ dpooled, const T* __restrict__ dskip, int ldskip,
+                                T* __restrict__ da, int B, int H, int W, int C) {
   constexpr int E = Vec16<T>::N;
   const int CG = C / E;
   const int QH = (H + 1) >> 1, QW = (W + 1) >> 1;
@@ -404,7 +422,20 @@ __global__ void pool_bwd_kernel(const T* __restrict__ a, const T* __restrict__ d
   Vec16<T> av[4];
   int arg[E];
   float dp[E];
-  if (full) {
+  if (full && argmax != nullptr) {
+    const long q = (((long)b * (H >> 1) + qy) * (W >> 1) + qx) * C + c0;
+#pragma unroll
+    for (int e = 0; e < E; e += 4) {
+      const unsigned int packed = *reinterpret_cast<const unsigned int*>(argmax + q + e);
+      arg[e] = packed & 255;
+      arg[e + 1] = (packed >> 8) & 255;
+      arg[e + 2] = (packed >> 16) & 255;
+      arg[e + 3] = packed >> 24;
+    }
+    Vec16<T> d = load16(dpooled + q);
+#pragma unroll
+    for (int e = 0; e < E; ++e) dp[e] = to_f32(d.v[e]);
+  } else if (full) {
     float mx[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -469,7 +500,8 @@ __global__ void upsample_concat_kernel(const T* __restrict__ low, int h, int w, 
                                        const T* __restrict__ skip, int ldskip, int C2, T* __restrict__ out,
                                        int B, int H, int W, float sy, float sx) {
   constexpr int E = Vec16<T>::N;
-  const int C = C1 + C2, CG = C / E, CG1 = C1 / E;
+  const int C = C1 + C2, CG1 = C1 / E;
+  const int CG = skip != nullptr ? C / E : CG1;   // without a skip only channels [0,C1) are written
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)B * H * W * CG) return;
   const int cg = idx % CG;
@@ -526,22 +558,54 @@ __global__ void upsample_bwd_kernel(const T* __restrict__ dout, int ldout, int H
   if (xlo < 0) xlo = 0;
   if (yhi > H - 1) yhi = H - 1;
   if (xhi > W - 1) xhi = W - 1;
-  for (int y = ylo; y <= yhi; ++y) {
-    int y0, y1;
-    float ly;
-    src_index(sy, y, h, y0, y1, ly);
-    const float wy = (y0 == i ? 1.f - ly : 0.f) + (y1 == i ? ly : 0.f);
-    if (wy == 0.f) continue;
-    for (int x = xlo; x <= xhi; ++x) {
+  // the column weights do not depend on the row: computed once (up to 8 candidate columns, which
+  // covers every up-sampling ratio; wider windows take the generic path below)
+  constexpr int MAXC = 8;
+  const int ncol = xhi - xlo + 1;
+  const T* base = dout + (long)b * H * W * ldout + cg * E;
+  if (ncol <= MAXC) {
+    float wxs[MAXC];
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
       int x0, x1;
       float lx;
-      src_index(sx, x, w, x0, x1, lx);
-      const float wx = (x0 == j ? 1.f - lx : 0.f) + (x1 == j ? lx : 0.f);
-      if (wx == 0.f) continue;
-      Vec16<T> v = load16(dout + (((long)b * H + y) * W + x) * ldout + cg * E);
-      const float wgt = wy * wx;
+      src_index(sx, xlo + k, w, x0, x1, lx);
+      wxs[k] = (k < ncol) ? (x0 == j ? 1.f - lx : 0.f) + (x1 == j ? lx : 0.f) : 0.f;
+    }
+    for (int y = ylo; y <= yhi; ++y) {
+      int y0, y1;
+      float ly;
+      src_index(sy, y, h, y0, y1, ly);
+      const float wy = (y0 == i ? 1.f - ly : 0.f) + (y1 == i ? ly : 0.f);
+      if (wy == 0.f) continue;
+      const T* row = base + ((long)y * W + xlo) * ldout;
 #pragma unroll
-      for (int e = 0; e < E; ++e) acc[e] += wgt * to_f32(v.v[e]);
+      for (int k = 0; k < MAXC; ++k) {
+        if (wxs[k] == 0.f) continue;
+        Vec16<T> v = load16(row + (long)k * ldout);
+        const float wgt = wy * wxs[k];
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] += wgt * to_f32(v.v[e]);
+      }
+    }
+  } else {
+    for (int y = ylo; y <= yhi; ++y) {
+      int y0, y1;
+      float ly;
+      src_index(sy, y, h, y0, y1, ly);
+      const float wy = (y0 == i ? 1.f - ly : 0.f) + (y1 == i ? ly : 0.f);
+      if (wy == 0.f) continue;
+      for (int x = xlo; x <= xhi; ++x) {
+        int x0, x1;
+        float lx;
+        src_index(sx, x, w, x0, x1, lx);
+        const float wx = (x0 == j ? 1.f - lx : 0.f) + (x1 == j ? lx : 0.f);
+        if (wx == 0.f) continue;
+        Vec16<T> v = load16(base + ((long)y * W + x) * ldout);
+        const float wgt = wy * wx;
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] += wgt * to_f32(v.v[e]);
+      }
     }
   }
   Vec16<T> o;
@@ -682,15 +746,20 @@ int unetk_bn_fold_eval(const float* gamma, const float* beta, const float* runni
   return UNETK_OK;
 }
 
-int unetk_bn_act_fwd(const void* y, void* a, void* pooled, int B, int H, int W, int C, const float* scale,
-                     const float* shift, const float* keep, int relu, int dtype, hipStream_t stream) {
+int unetk_bn_act_fwd(const void* y, void* a, int lda, void* pooled, unsigned char* argmax, int B, int H, int W,
+                     int C, const float* scale, const float* shift, const float* keep, int relu, int dtype,
+                     hipStream_t stream) {
   UNETK_CHECK_ARG(y && (a || pooled), "bn_act_fwd: null pointer");
+  UNETK_CHECK_ARG(argmax == nullptr || pooled != nullptr, "bn_act_fwd: argmax needs the pooled output");
   CHECK_DTYPE("bn_act_fwd", dtype);
   CHECK_VEC("bn_act_fwd", dtype, C);
   const int E = dtype == UNETK_BF16 ? 8 : 4;
+  UNETK_CHECK_ARG(a == nullptr || (lda >= C && lda % E == 0 && ((uintptr_t)a % 16) == 0),
+                  "bn_act_fwd: output stride %d (>= C, multiple of %d, 16-byte aligned base)", lda, E);
   const long total = (long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / E);
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3(cdiv(total, 256)), dim3(256), 0, stream,
-                                       (const T*)y, (T*)a, (T*)pooled, B, H, W, C, scale, shift, keep, relu));
+                                       (const T*)y, (T*)a, lda, (T*)pooled, argmax, B, H, W, C, scale, shift,
+                                       keep, relu));
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }
@@ -745,30 +814,30 @@ int unetk_bn_act_bwd(const void* g, const void* y, void* dy, int B, int H, int W
   return UNETK_OK;
 }
 
-int unetk_pool_bwd(const void* a, const void* dpooled, const void* dskip, int ldskip, void* da, int B,
-                   int H, int W, int C, int dtype, hipStream_t stream) {
-  UNETK_CHECK_ARG(a && dpooled && da, "pool_bwd: null pointer");
+int unetk_pool_bwd(const void* a, const unsigned char* argmax, const void* dpooled, const void* dskip,
+                   int ldskip, void* da, int B, int H, int W, int C, int dtype, hipStream_t stream) {
+  UNETK_CHECK_ARG((a || argmax) && dpooled && da, "pool_bwd: null pointer");
   CHECK_DTYPE("pool_bwd", dtype);
   CHECK_VEC("pool_bwd", dtype, C);
   const int E = dtype == UNETK_BF16 ? 8 : 4;
   UNETK_CHECK_ARG(dskip == nullptr || ldskip % E == 0, "pool_bwd: skip stride misaligned");
   const long total = (long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / E);
   DISPATCH_T(dtype, hipLaunchKernelGGL(pool_bwd_kernel<T>, dim3(cdiv(total, 256)), dim3(256), 0, stream,
-                                       (const T*)a, (const T*)dpooled, (const T*)dskip, ldskip, (T*)da, B, H,
-                                       W, C));
+                                       (const T*)a, argmax, (const T*)dpooled, (const T*)dskip, ldskip,
+                                       (T*)da, B, H, W, C));
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }
 
 int unetk_upsample_concat_fwd(const void* low, int h, int w, int C1, const void* skip, int ldskip, int C2,
                               void* out, int B, int H, int W, int dtype, hipStream_t stream) {
-  UNETK_CHECK_ARG(low && out && (skip || C2 == 0), "upsample_concat_fwd: null pointer");
+  UNETK_CHECK_ARG(low && out, "upsample_concat_fwd: null pointer");
   CHECK_DTYPE("upsample_concat_fwd", dtype);
   CHECK_VEC("upsample_concat_fwd", dtype, C1);
   CHECK_VEC("upsample_concat_fwd", dtype, C2);
   const int E = dtype == UNETK_BF16 ? 8 : 4;
   const float sy = (float)h / (float)H, sx = (float)w / (float)W;
-  const long total = (long)B * H * W * ((C1 + C2) / E);
+  const long total = (long)B * H * W * ((skip ? C1 + C2 : C1) / E);
   DISPATCH_T(dtype, hipLaunchKernelGGL(upsample_concat_kernel<T>, dim3(cdiv(total, 256)), dim3(256), 0,
                                        stream, (const T*)low, h, w, C1, (const T*)skip, ldskip, C2, (T*)out,
                                        B, H, W, sy, sx));

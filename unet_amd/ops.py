@@ -154,12 +154,19 @@ def bn_fold_eval(gamma, beta, running_mean, running_var, conv_bias=None, eps=BN_
     return out[0], out[1]
 
 
-def bn_act_fwd(y, scale, shift, keep=None, relu=True, pool=False, write_a=True):
+def bn_act_fwd(y, scale, shift, keep=None, relu=True, pool=False, write_a=True, out=None,
+               want_argmax=False):
+    """a = relu(y*scale+shift)*keep (+ its 2x2 max-pool).  ``out`` may be a channel slice of a wider
+    NHWC buffer (the skip half of a decoder's concat input).  With ``want_argmax`` the result is
+    (a, pooled, argmax): the uint8 map of first maxima that ``pool_bwd`` takes instead of ``a``."""
     B, H, W, C = y.shape
-    a = torch.empty_like(y) if write_a else None
+    a = out if out is not None else (torch.empty_like(y) if write_a else None)
     pooled = torch.empty((B, H // 2, W // 2, C), dtype=y.dtype, device=y.device) if pool else None
-    call("unetk_bn_act_fwd", ptr(y), ptr(a), ptr(pooled), B, H, W, C, ptr(scale), ptr(shift), ptr(keep),
-         1 if relu else 0, dtype_code(y.dtype), stream())
+    argmax = torch.empty((B, H // 2, W // 2, C), dtype=torch.uint8, device=y.device) if (pool and want_argmax) else None
+    call("unetk_bn_act_fwd", ptr(y), ptr(a), a.stride(2) if a is not None else 0, ptr(pooled), ptr(argmax),
+         B, H, W, C, ptr(scale), ptr(shift), ptr(keep), 1 if relu else 0, dtype_code(y.dtype), stream())
+    if want_argmax:
+        return a, pooled, argmax
     return a, pooled
 
 
@@ -186,12 +193,18 @@ def bn_act_bwd(g, y, scale, shift, mean, invstd, keep=None, relu=True, dgamma=No
     return dy, dgamma, dbeta
 
 
-def pool_bwd(a, dpooled, dskip=None):
-    B, H, W, C = a.shape
-    da = torch.empty_like(a)
+def pool_bwd(a, dpooled, dskip=None, argmax=None):
+    """da = dskip + dpooled routed to the first maximum of each quad (from ``argmax`` when given,
+    else recomputed from ``a``, which may then be None)."""
+    B, h2, w2, C = dpooled.shape
+    if a is not None:
+        _, H, W, _ = a.shape
+    else:
+        _, H, W, _ = dskip.shape
+    da = torch.empty((B, H, W, C), dtype=dpooled.dtype, device=dpooled.device)
     # dskip may be a channel slice of a wider buffer: its pixel stride is what the kernel needs
-    call("unetk_pool_bwd", ptr(a), ptr(dpooled), ptr(dskip), dskip.stride(2) if dskip is not None else 0,
-         ptr(da), B, H, W, C, dtype_code(a.dtype), stream())
+    call("unetk_pool_bwd", ptr(a) if argmax is None else None, ptr(argmax), ptr(dpooled), ptr(dskip),
+         dskip.stride(2) if dskip is not None else 0, ptr(da), B, H, W, C, dtype_code(dpooled.dtype), stream())
     return da
 
 
@@ -200,9 +213,20 @@ def upsample_concat(low, skip):
     B, h, w, C1 = low.shape
     _, H, W, C2 = skip.shape
     out = torch.empty((B, H, W, C1 + C2), dtype=low.dtype, device=low.device)
-    call("unetk_upsample_concat_fwd", ptr(low), h, w, C1, ptr(skip), C2, C2, ptr(out), B, H, W,
+    call("unetk_upsample_concat_fwd", ptr(low), h, w, C1, ptr(skip), skip.stride(2), C2, ptr(out), B, H, W,
          dtype_code(low.dtype), stream())
     return out
+
+
+def upsample_into(low, cat):
+    """Writes bilinear_resize(low -> cat's H,W) into channels [0,C1) of the dense concat buffer
+    ``cat`` (B,H,W,C1+C2) whose skip half is already in place."""
+    B, h, w, C1 = low.shape
+    _, H, W, C = cat.shape
+    assert cat.is_contiguous() and C > C1
+    call("unetk_upsample_concat_fwd", ptr(low), h, w, C1, None, 0, C - C1, ptr(cat), B, H, W,
+         dtype_code(low.dtype), stream())
+    return cat
 
 
 def upsample_bwd(dcat, C1, h, w):

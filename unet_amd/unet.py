@@ -174,14 +174,17 @@ class _UNetTrainFn(torch.autograd.Function):
         h = ops.nchw_to_nhwc(x.detach(), dt)
         saved["x"] = h
 
-        def block(name, t, keep, pool):
+        def block(name, t, keep, pool, cat_c1=0):
+            """conv-BN-ReLU twice (+Dropout2d mask, + 2x2 max-pool for encoder blocks).  An encoder
+            block writes its output straight into the skip half of its decoder's concat buffer
+            (channels [cat_c1:]) and keeps the pooling argmax map for the backward."""
             seq = getattr(model, name)
             units = []
-            pooled = None
+            pooled = argmax = cat = None
             for u, (ci, bi) in enumerate(((0, 1), (3, 4))):
                 bn = seq[bi]
                 y, stats = ops.conv_fwd(t, pk[(name, ci)], want_stats=True)
-                Bn, H, W, _ = y.shape
+                Bn, H, W, C = y.shape
                 mean, invstd, sc, sh = ops.bn_finalize(
                     stats, Bn * H * W, bn.weight, bn.bias,
                     bn.running_mean if bn.track_running_stats else None,
@@ -190,25 +193,32 @@ class _UNetTrainFn(torch.autograd.Function):
                 if bn.track_running_stats:
                     bn.num_batches_tracked += 1
                 last = u == 1
-                a, p = ops.bn_act_fwd(y, sc, sh, keep if last else None, relu=True, pool=pool and last)
+                if last and pool:
+                    cat = torch.empty((Bn, H, W, cat_c1 + C), dtype=y.dtype, device=y.device)
+                    a, pooled, argmax = ops.bn_act_fwd(y, sc, sh, keep, relu=True, pool=True,
+                                                       out=cat[..., cat_c1:], want_argmax=True)
+                else:
+                    a, _ = ops.bn_act_fwd(y, sc, sh, keep if last else None, relu=True)
                 units.append((t, y, mean, invstd, sc, sh))
                 t = a
-                if last:
-                    pooled = p
-            saved[name] = (units, t, keep)
-            return t, pooled
+            saved[name] = (units, argmax, keep)
+            return t, pooled, cat
 
-        e1, p1 = block("encoder1", h, masks[0], True)
-        e2, p2 = block("encoder2", p1, masks[1], True)
-        e3, p3 = block("encoder3", p2, masks[2], True)
-        e4, p4 = block("encoder4", p3, masks[3], True)
-        d, _ = block("bottleneck", p4, masks[4], False)
-        for i, (name, skip) in enumerate((("decoder4", e4), ("decoder3", e3), ("decoder2", e2),
-                                          ("decoder1", e1))):
+        def up_channels(dec, enc):      # channels of the resized (non-skip) input of a decoder block
+            return getattr(model, dec)[0].in_channels - getattr(model, enc)[3].out_channels
+
+        _, p1, cat1 = block("encoder1", h, masks[0], True, up_channels("decoder1", "encoder1"))
+        _, p2, cat2 = block("encoder2", p1, masks[1], True, up_channels("decoder2", "encoder2"))
+        _, p3, cat3 = block("encoder3", p2, masks[2], True, up_channels("decoder3", "encoder3"))
+        _, p4, cat4 = block("encoder4", p3, masks[3], True, up_channels("decoder4", "encoder4"))
+        d, _, _ = block("bottleneck", p4, masks[4], False)
+        for i, (name, cat) in enumerate((("decoder4", cat4), ("decoder3", cat3), ("decoder2", cat2),
+                                         ("decoder1", cat1))):
             low_hw = d.shape[1:3]
-            cat = ops.upsample_concat(d, skip)
             saved[name + ".low"] = (low_hw, d.shape[3])
-            d, _ = block(name, cat, masks[5 + i], False)
+            ops.upsample_into(d, cat)
+            d, _, _ = block(name, cat, masks[5 + i], False)
+        saved["head_in"] = d
         out = ops.head1x1_fwd(d, model.conv.weight, model.conv.bias)
         ctx.model = model
         ctx.saved = saved
@@ -230,13 +240,12 @@ class _UNetTrainFn(torch.autograd.Function):
         held = []          # operands of side-stream kernels stay allocated until the join
 
         # final 1x1 conv
-        units_d1, a_d1, _ = saved["decoder1"]
-        g, dw, db = ops.head1x1_bwd(a_d1, model.conv.weight, dout)
+        g, dw, db = ops.head1x1_bwd(saved["head_in"], model.conv.weight, dout)
         grads["conv.weight"], grads["conv.bias"] = dw, db
 
         def block_bwd(name, g, need_dx=True, split=0):
             seq = getattr(model, name)
-            units, a_out, keep = saved[name]
+            units, _, keep = saved[name]
             for u in (1, 0):
                 ci, bi = ((0, 1), (3, 4))[u]
                 t_in, y, mean, invstd, sc, sh = units[u]
@@ -276,8 +285,7 @@ class _UNetTrainFn(torch.autograd.Function):
             g = ops.upsample_bwd(g_up, C1, lh, lw)
         g = block_bwd("bottleneck", g)
         for enc in reversed(enc_names):
-            _, a_enc, _ = saved[enc]
-            g = ops.pool_bwd(a_enc, g, dskips[enc])
+            g = ops.pool_bwd(None, g, dskips[enc], argmax=saved[enc][1])
             g = block_bwd(enc, g, need_dx=(enc != "encoder1") or ctx.need_dx)
         dx = None
         if ctx.need_dx:
