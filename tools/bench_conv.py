@@ -21,6 +21,9 @@ def timeit(fn, n=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 
+only = os.environ.get("LAYERS")          # e.g. LAYERS=dec3.0,enc2.3 to profile a few shapes
+if only:
+    layers = [l for l in layers if l[0] in only.split(",")]
 tot = {"fwd": 0, "dgrad": 0, "wgrad": 0}
 for name, hw, ci, co in layers:
     x = torch.randn(B, hw, hw, ci, device="cuda").to(dt)

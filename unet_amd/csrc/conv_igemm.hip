@@ -58,6 +58,20 @@ constexpr int ROWB = 64;   // LDS bytes per staged row (unpadded, slots swizzled
 
 
 
+// Workgroup barrier that first waits until at most n of this wave's vector-memory operations are
+// still outstanding.  Loads complete in issue order, so with n = the number of DMA instructions
+// the wave issued after the ones it needs now, the needed ones have landed while the newer ones
+// stay in flight.  (__syncthreads() would drain everything.)
+__device__ __forceinline__ void wait_vm_barrier(int n) {
+#define UNETK_WVB(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_barrier" ::: "memory"); break;
+  switch (n) {
+    UNETK_WVB(1) UNETK_WVB(2) UNETK_WVB(3) UNETK_WVB(4) UNETK_WVB(5) UNETK_WVB(6) UNETK_WVB(7) UNETK_WVB(8)
+    UNETK_WVB(9) UNETK_WVB(10) UNETK_WVB(11) UNETK_WVB(12)
+    default: asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); break;
+  }
+#undef UNETK_WVB
+}
+
 __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
@@ -164,43 +178,77 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
   const int nphase = a.nchunks * KS;
   issue_halo(0);
   issue_w(0);
+  // halo pieces this wave issues per chunk, and whether a halo issued one phase ago is in flight
+  const int my_halo = (HINSTR - wave + 3) / 4;
+  bool halo_flying = false;
+
+  // bf16 fragment addresses without per-read arithmetic.  A fragment read is row (R + l15), 16-byte
+  // slot (q ^ swz(row)); R is wave-uniform and, as 18*4*wave and BN are multiples of 8, R mod 8 is a
+  // compile-time constant c of the unrolled loops, and swz() only looks at bit 2 of the row.  So
+  // the per-lane part of the address takes 8 values (one per c) for the halo and one for the
+  // weights; everything else is an immediate offset of the ds_read.
+  const int l15 = lane & 15, q = lane >> 4;
+  int a_lane[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+    a_lane[c] = (4 * wave * (KS == 3 ? HALO : 16) + l15) * ROWB + ((q ^ swz(c + l15)) * 16);
+  const int w_lane = l15 * ROWB + ((q ^ swz(l15)) * 16);
+
 #pragma unroll 1
-  for (int phase = 0; phase < nphase; ++phase) {
-    const int ch = phase / KS, ky = phase - ch * KS;
-    // the DMA of this phase has landed for every wave, and everyone is done with phase-1's buffers
-    __syncthreads();
-    if (!HDB && ky == 0 && ch > 0) {
-      // single halo buffer (more workgroups per CU instead): the chunk is fetched only now that
-      // every wave is done with the previous one; other workgroups on the CU cover the wait
-      issue_halo(ch);
-      __syncthreads();
-    }
-    if (phase + 1 < nphase) {
-      issue_w(phase + 1);
-      if (HDB && ky == KS - 1) issue_halo(ch + 1);
-    }
+  for (int ch = 0; ch < a.nchunks; ++ch) {
     const char* lds_halo = lds + (HDB ? (ch & 1) : 0) * HBUF;
-    const char* lds_w = lds + NHB * HBUF + (phase & 1) * WBUF;
 #pragma unroll
-    for (int kx = 0; kx < KS; ++kx) {
+    for (int ky = 0; ky < KS; ++ky) {
+      const int phase = ch * KS + ky;
+      // The weights of this phase (and at ky == 0 its halo) have landed for every wave, and everyone
+      // is done with phase-1's buffers.  With two halo buffers the next chunk's halo is issued in the
+      // chunk's first phase, after that phase's weight prefetch: at the next barrier it is the newest
+      // thing in flight and may stay there; the barrier after that drains it (two phases of cover).
+      if (HDB) wait_vm_barrier((KS == 3 && ky == 1 && halo_flying) ? my_halo : 0);
+      else __syncthreads();
+      if (!HDB && ky == 0 && ch > 0) {
+        // single halo buffer (more workgroups per CU instead): the chunk is fetched only now that
+        // every wave is done with the previous one; other workgroups on the CU cover the wait
+        issue_halo(ch);
+        __syncthreads();
+      }
+      if (phase + 1 < nphase) issue_w(phase + 1);
+      if (HDB && ky == 0) {
+        halo_flying = ch + 1 < a.nchunks;
+        if (halo_flying) issue_halo(ch + 1);
+      }
+      const char* lds_w = lds + NHB * HBUF + (phase & 1) * WBUF;
 #pragma unroll
-      for (int ks = 0; ks < M::KSTEPS; ++ks) {
-        typename M::frag af[4], bfr[NT];
+      for (int kx = 0; kx < KS; ++kx) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int prow = (KS == 3) ? ((4 * wave + i + ky) * HALO + kx + (lane & 15))
-                                     : ((4 * wave + i) * 16 + (lane & 15));
-          af[i] = M::load_swz(lds_halo + prow * ROWB, ks, lane, swz(prow));
+        for (int ks = 0; ks < M::KSTEPS; ++ks) {
+          typename M::frag af[4], bfr[NT];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if constexpr (sizeof(T) == 2) {
+              const int c = (KS == 3) ? ((2 * (i + ky) + kx) & 7) : 0;
+              const int imm = (KS == 3) ? ((i + ky) * HALO + kx) * ROWB : (i * 16) * ROWB;
+              af[i] = *reinterpret_cast<const typename M::frag*>(lds_halo + a_lane[c] + imm);
+            } else {
+              const int prow = (KS == 3) ? ((4 * wave + i + ky) * HALO + kx + (lane & 15))
+                                         : ((4 * wave + i) * 16 + (lane & 15));
+              af[i] = M::load_swz(lds_halo + prow * ROWB, ks, lane, swz(prow));
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            if constexpr (sizeof(T) == 2) {
+              bfr[j] = *reinterpret_cast<const typename M::frag*>(lds_w + w_lane + (kx * BN + j * 16) * ROWB);
+            } else {
+              const int wrow = kx * BN + j * 16 + (lane & 15);
+              bfr[j] = M::load_swz(lds_w + wrow * ROWB, ks, lane, swz(wrow));
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = M::mma(af[i], bfr[j], acc[i][j]);
         }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int wrow = kx * BN + j * 16 + (lane & 15);
-          bfr[j] = M::load_swz(lds_w + wrow * ROWB, ks, lane, swz(wrow));
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = M::mma(af[i], bfr[j], acc[i][j]);
       }
     }
   }
@@ -315,7 +363,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
 }
 
 template <typename T, int NT, int KS>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_igemm_kernel(ConvArgs a) {
   conv_igemm_body<T, NT, KS, true>(a);
 }
 
@@ -389,6 +437,7 @@ inline int epp_of(int dtype) { return dtype == UNETK_BF16 ? 8 : 4; }
 extern "C" {
 
 int unetk_conv_pick_bn(int Co) {
+  if (getenv("UNETK_FORCE_BN48") && Co % 48 == 0) return 48;
   if (Co % 96 == 0) return 96;
   if (Co % 64 == 0) return 64;
   if (Co % 48 == 0) return 48;
