@@ -144,35 +144,77 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const T* zero = reinterpret_cast<const T*>(conv_zero_page);
+  // DMA source addresses.  What depends on the lane and the piece but not on the tile or the chunk
+  // is computed once: for halo piece k of this wave the pixel's halo coordinates, its element
+  // offset from the halo's first pixel and its channel slot.  Issuing a piece then costs a few
+  // compares and one 64-bit add instead of divisions and multiplies between the MFMAs.
+  constexpr int HPW = (HINSTR + 3) / 4;                 // halo pieces per wave (at most)
+  int h_rel[HPW], h_yx[HPW], h_slot[HPW];
+#pragma unroll
+  for (int k = 0; k < (HDB ? HPW : 0); ++k) {
+    const int part = (wave + 4 * k) * 64 + lane;
+    const int pix = part >> 2;
+    h_slot[k] = ((part & 3) ^ swz(pix)) * EPP;
+    if (KS == 3) {
+      const int hy = pix / HALO, hx = pix - hy * HALO;
+      h_rel[k] = (hy * a.W + hx) * a.ldin + h_slot[k];
+      h_yx[k] = (pix < HPIX) ? ((hy << 16) | hx) : (0x7fff << 16);   // rows past the halo never pass the test
+    } else {
+      h_rel[k] = pix * a.ldin + h_slot[k];
+      h_yx[k] = pix;
+    }
+  }
+  // first halo pixel of the tile (may lie outside the image: only valid lanes add to it)
+  const T* halo_base = (KS == 3) ? in + (((long)b * a.H + (y0 - 1)) * a.W + (x0 - 1)) * a.ldin : in + p0 * a.ldin;
+  const unsigned rows_left = (KS == 3) ? 0u : (unsigned)((npix - p0 < 256) ? (npix - p0) : 256);
   auto issue_halo = [&](int ch) {
     char* dst = lds + (HDB ? (ch & 1) : 0) * HBUF;
     const int c0 = ch * KC;
-    for (int i = wave; i < HINSTR; i += 4) {
-      const int part = i * 64 + lane;
-      const int pix = part >> 2;
-      const int c = c0 + ((part & 3) ^ swz(pix)) * EPP;
-      const T* src = zero;
-      if (KS == 3) {
-        const int hy = pix / HALO, hx = pix - hy * HALO;
-        const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-        if (pix < HPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.Ci)
-          src = in + (((long)b * a.H + gy) * a.W + gx) * a.ldin + c;
-      } else {
-        const long p = p0 + pix;
-        if (p < npix && c < a.Ci) src = in + p * a.ldin + c;
+    const T* base = halo_base + c0;
+    const int climit = a.Ci - c0;                         // channel slots below this exist
+    if constexpr (!HDB) {
+      // the 4-workgroups-per-CU variant has no registers to spare for the tables: recompute
+      for (int i = wave; i < HINSTR; i += 4) {
+        const int part = i * 64 + lane;
+        const int pix = part >> 2;
+        const int c = c0 + ((part & 3) ^ swz(pix)) * EPP;
+        const T* src = zero;
+        if (KS == 3) {
+          const int hy = pix / HALO, hx = pix - hy * HALO;
+          const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+          if (pix < HPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.Ci)
+            src = in + (((long)b * a.H + gy) * a.W + gx) * a.ldin + c;
+        } else {
+          const long p = p0 + pix;
+          if (p < npix && c < a.Ci) src = in + p * a.ldin + c;
+        }
+        glds16(src, dst + i * 1024);
       }
-      glds16(src, dst + i * 1024);
+      return;
+    }
+#pragma unroll
+    for (int k = 0; k < HPW; ++k) {
+      const int i = wave + 4 * k;
+      if (i < HINSTR) {
+        bool ok;
+        if (KS == 3) {
+          const unsigned gy = (unsigned)(y0 - 1 + (h_yx[k] >> 16)), gx = (unsigned)(x0 - 1 + (h_yx[k] & 0xffff));
+          ok = gy < (unsigned)a.H && gx < (unsigned)a.W && h_slot[k] < climit;
+        } else {
+          ok = (unsigned)h_yx[k] < rows_left && h_slot[k] < climit;
+        }
+        const T* src = ok ? base + h_rel[k] : zero;
+        glds16(src, dst + i * 1024);
+      }
     }
   };
+  // weights: piece i of a slab is 1 KiB further on; the lane's offset inside a piece is fixed
+  const int w_rel = (lane >> 2) * KC + ((lane & 3) ^ swz(lane >> 2)) * EPP;
   auto issue_w = [&](int phase) {
     const int ch = phase / KS, ky = phase - ch * KS;
     char* dst = lds + NHB * HBUF + (phase & 1) * WBUF;
-    const T* wsrc = wp + ((((long)nb * a.nchunks + ch) * TAPS + ky * KS) * BN) * KC;
-    for (int i = wave; i < WINSTR; i += 4) {
-      const int part = i * 64 + lane;
-      const int row = part >> 2;
-      glds16(wsrc + row * KC + ((part & 3) ^ swz(row)) * EPP, dst + i * 1024);
-    }
+    const T* wsrc = wp + ((((long)nb * a.nchunks + ch) * TAPS + ky * KS) * BN) * KC + w_rel;
+    for (int i = wave; i < WINSTR; i += 4) glds16(wsrc + i * (1024 / (int)sizeof(T)), dst + i * 1024);
   };
 
   const int nphase = a.nchunks * KS;
