@@ -97,7 +97,9 @@ class OptimizedUNet(nn.Module):
         return masks
 
 
-OVERLAP_WGRAD = os.environ.get("UNETK_OVERLAP_WGRAD", "1") != "0"
+# Weight gradients on a second HIP stream: measured neutral on MI355X once both kernel families ran
+# near their own limits (they compete for the same CUs), so it is off unless asked for.
+OVERLAP_WGRAD = os.environ.get("UNETK_OVERLAP_WGRAD", "0") != "0"
 _SIDE_STREAMS = {}
 
 
@@ -233,8 +235,8 @@ class _UNetTrainFn(torch.autograd.Function):
         pkT = _pack_all(model, dt, True)
         grads = {}
         # Weight gradients are off the critical chain (dgrad -> BatchNorm backward -> dgrad ...):
-        # they run on a second HIP stream so the MFMA-bound wgrad kernels overlap the HBM-bound
-        # BatchNorm / pool / resize backward passes of the following layers.
+        # optionally they run on a second HIP stream, overlapping the HBM-bound BatchNorm / pool /
+        # resize backward passes of the following layers.
         main = torch.cuda.current_stream()
         side = _side_stream(dout.device) if OVERLAP_WGRAD else main
         held = []          # operands of side-stream kernels stay allocated until the join
@@ -253,27 +255,37 @@ class _UNetTrainFn(torch.autograd.Function):
                                                    keep if u == 1 else None, relu=True)
                 grads[f"{name}.{bi}.weight"], grads[f"{name}.{bi}.bias"] = dgamma, dbeta
                 conv = seq[ci]
+                def wgrad():
+                    return ops.conv_wgrad(t_in, dy, conv.in_channels, conv.out_channels, 3)
+
+                def dgrad():
+                    if not (u == 1 or need_dx):
+                        return None
+                    pw = pkT[(name, ci)]
+                    # the first conv of a decoder block read cat([up, skip]): its data gradient comes
+                    # out as two dense tensors (when the boundary falls on a channel block)
+                    sp = split if (u == 0 and split and split % pw.bn == 0) else 0
+                    gg, _ = ops.conv_fwd(dy, pw, split=sp)
+                    if u == 0 and split and not sp:
+                        gg = (gg[..., :split], gg[..., split:])
+                    return gg
+
                 if side is main:
-                    dw = ops.conv_wgrad(t_in, dy, conv.in_channels, conv.out_channels, 3)
+                    dw = wgrad()
+                    g = dgrad()
                 else:
+                    # the side stream may start this weight gradient once the data-gradient conv of
+                    # the same layer is through: it then shares the chip with the HBM-bound
+                    # BatchNorm backward of the next layer rather than with another MFMA kernel
+                    g = dgrad()
                     ready = torch.cuda.Event()
                     ready.record(main)
                     held.append(dy)
                     with torch.cuda.stream(side):
                         side.wait_event(ready)
-                        dw = ops.conv_wgrad(t_in, dy, conv.in_channels, conv.out_channels, 3)
+                        dw = wgrad()
                     dw.record_stream(main)
                 grads[f"{name}.{ci}.weight"] = dw
-                if u == 1 or need_dx:
-                    pw = pkT[(name, ci)]
-                    # the first conv of a decoder block read cat([up, skip]): its data gradient comes
-                    # out as two dense tensors (when the boundary falls on a channel block)
-                    sp = split if (u == 0 and split and split % pw.bn == 0) else 0
-                    g, _ = ops.conv_fwd(dy, pw, split=sp)
-                    if u == 0 and split and not sp:
-                        g = (g[..., :split], g[..., split:])
-                else:
-                    g = None
             return g
 
         enc_names = ("encoder1", "encoder2", "encoder3", "encoder4")
