@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--workload", default="train", choices=["train", "swin", "predict"],
+                    help="train: UNet step (headline); swin: Swin-UNet step; predict: tiled large-area inference")
+    ap.add_argument("--grid", type=int, default=8192, help="predict: side of the synthetic grid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -143,6 +146,120 @@ def cpu_baseline(batch, size):
             "sample": f"torch-CPU fp32 oracle, batch {batch} of 4x{size}x{size}, fwd+loss+bwd, best of 2 after 1 warm-up"}
 
 
+def barrier_sync(world):
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        torch.cuda.synchronize()
+
+
+def timed(fn, steps, warmup, world, dev):
+    """warmup untimed calls, then `steps` calls between barriers; max over ranks, seconds."""
+    for _ in range(warmup):
+        fn()
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    barrier_sync(world)
+    el = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = t.item()
+    return el
+
+
+def run_predict(args, rank, world, dev, dt):
+    """Tiled large-area inference (BASELINE config 4): UNet(4,1,48) eval over a synthetic grid,
+    256-px tiles with 50 % overlap, Gaussian blend; tile rows sharded over the ranks (strong scaling)."""
+    import numpy as np
+    from oracle import weights as W
+    from unet_amd import OptimizedUNet
+    from unet_amd.predictor import LargeAreaPredictor, LargeAreaPredictionConfig
+    model = OptimizedUNet(4, 1, 48, compute_dtype=dt)
+    model.load_state_dict(W.fill_state_dict(W.unet_template(4, 1, 48), seed=42))
+    model = model.to(dev).eval()
+
+    class Cfg(LargeAreaPredictionConfig):
+        PATCH_SIZE = 256
+        STRIDE = 128
+        OUTPUT_DIR = "/tmp/unetk_bench_pred"
+    g = torch.Generator(device="cpu").manual_seed(7)
+    feats = torch.randn((4, args.grid, args.grid), generator=g).to(dev)
+    pred = LargeAreaPredictor(Cfg)
+    with torch.no_grad():
+        el = timed(lambda: pred.predict_device(model, feats), args.steps, args.warmup, world, dev)
+    ms = el / args.steps * 1e3
+    mpix = args.grid * args.grid / 1e6
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import tile_oracle, unet_oracle
+        torch.set_num_threads(min(os.cpu_count() or 1, 16))
+        sd = W.fill_state_dict(W.unet_template(4, 1, 48), seed=42)
+        n = 768
+        fs = {v: feats[i, :n, :n].cpu().numpy() for i, v in enumerate(tile_oracle.FEATURE_VARS)}
+        fn = lambda x: unet_oracle.unet_forward(sd, torch.from_numpy(x), training=False)[0].numpy()
+        t0 = time.perf_counter()
+        tile_oracle.predict_large_area(fn, fs, 256, 128, 16)
+        t = time.perf_counter() - t0
+        cpu = {"value": round(n * n / 1e6 / t, 4), "unit": "Mpix/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"numpy/torch-CPU oracle on a {n}x{n} corner of the same grid (25 tiles)"}
+    if rank == 0:
+        ntile = ((args.grid - 256) // 128 + 1) ** 2
+        print(json.dumps({
+            "metric": "tiled-predict Mpix/s", "value": round(mpix / (ms * 1e-3), 2), "unit": "Mpix/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": f"LargeAreaPredictor over a {args.grid}x{args.grid} grid, 256-px tiles, stride 128 "
+                                   f"({ntile} tiles), UNet(4,1,48) eval, Gaussian blend",
+                       "parallelism": f"tile-row bands over {world} GPU(s)"},
+            "roofline": None, "cpu_baseline": cpu}), flush=True)
+
+
+def run_swin(args, rank, world, dev, dt):
+    """Swin-UNet training step (BASELINE config 3): window 8, shifted windows, 256x256 input."""
+    from oracle import swin_oracle
+    from oracle import weights as W
+    from unet_amd.swin import SwinUNet
+    cfg = dict(swin_oracle.DEFAULT_CONFIG)
+    model = SwinUNet(cfg, compute_dtype=dt)
+    model.load_state_dict(W.fill_state_dict(swin_oracle.swin_template(cfg), seed=42))
+    model = model.to(dev).train()
+    B = args.batch
+    x, _, _ = W.synthetic_batch(B, 4, args.size, args.size, seed=42 + rank)
+    x = x.to(dev)
+    tgt = torch.randn((B, 1, args.size // 2, args.size // 2), device=dev)
+    reducer = None
+    if world > 1:
+        from unet_amd.dist import GradReducer
+        reducer = GradReducer(model)
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        loss = ((model(x) - tgt) ** 2).mean()
+        loss.backward()
+        if reducer is not None:
+            reducer.allreduce()
+
+    el = timed(step, args.steps, args.warmup, world, dev)
+    ms = el / args.steps * 1e3
+    if rank == 0:
+        print(json.dumps({
+            "metric": "train patches/s (fwd+bwd)", "value": round(world * B * args.steps / el, 2), "unit": "patches/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": f"SwinUNet (embed 96, depths 2-2-6-2, window 8) training step fwd+MSE+bwd, batch {B}/GPU "
+                                   f"of 4x{args.size}x{args.size}", "global_batch": world * B,
+                       "parallelism": f"dp{world}" if world > 1 else "single"},
+            "roofline": None, "cpu_baseline": None}), flush=True)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -156,6 +273,12 @@ def main():
     from oracle import weights as W
     from unet_amd import OptimizedUNet
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    if args.workload != "train":
+        (run_predict if args.workload == "predict" else run_swin)(args, rank, world, dev, dt)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     model = OptimizedUNet(4, 1, 48, compute_dtype=dt)
     model.load_state_dict(W.fill_state_dict(W.unet_template(4, 1, 48), seed=42))
     model = model.to(dev).train()
