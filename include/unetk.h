@@ -86,10 +86,10 @@ int unetk_bn_fold_eval(const float* gamma, const float* beta, const float* runni
                        float* shift, int C, unetk_stream_t stream);
 /* a = relu(y*scale+shift) * keep[b][c]; pooled (nullable) = 2x2 max of a.
  * scale/shift null = identity, a null = only the pooled output is written (plain MaxPool2d).
- * a has row stride lda (it may be the skip slice of the decoder's concat buffer, which saves the
+ * y has row stride ldy; a has row stride lda (it may be the skip slice of the decoder's concat buffer, which saves the
  * torch.cat copy of training.py:505).  argmax (nullable, [B][H/2][W/2][C] bytes) receives the
  * position 0..3 of the first maximum of each quad, for unetk_pool_bwd. */
-int unetk_bn_act_fwd(const void* y, void* a, int lda, void* pooled, unsigned char* argmax, int B, int H,
+int unetk_bn_act_fwd(const void* y, int ldy, void* a, int lda, void* pooled, unsigned char* argmax, int B, int H,
                      int W, int C, const float* scale, const float* shift, const float* keep, int relu,
                      int dtype, unetk_stream_t stream);
 int unetk_reduce_num_partials(int64_t npix);

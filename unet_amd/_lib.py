@@ -43,7 +43,7 @@ _SIGNATURES = {
     "unetk_nhwc_to_nchw": (I, [P, I, P, I, I, I, I, I, P]),
     "unetk_bn_finalize": (I, [P, I, I, L, P, P, F, F, P, P, P, P, P, P, P]),
     "unetk_bn_fold_eval": (I, [P, P, P, P, F, P, P, P, I, P]),
-    "unetk_bn_act_fwd": (I, [P, P, I, P, P, I, I, I, I, P, P, P, I, I, P]),
+    "unetk_bn_act_fwd": (I, [P, I, P, I, P, P, I, I, I, I, P, P, P, I, I, P]),
     "unetk_reduce_num_partials": (I, [L]),
     "unetk_bn_act_bwd": (I, [P, P, P, I, I, I, I, P, P, P, P, P, I, P, P, I, P, P, I, P]),
     "unetk_pool_bwd": (I, [P, P, P, P, I, P, I, I, I, I, I, P]),

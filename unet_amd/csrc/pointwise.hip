@@ -123,7 +123,8 @@ __global__ void bn_fold_eval_kernel(const float* gamma, const float* beta, const
 // buffer (row stride lda); argmax (nullable) receives, per pooled element, the position 0..3
 // (row-major in the quad) of its first maximum, which is all the pooling backward needs.
 template <typename T>
-__global__ void bn_act_fwd_kernel(const T* __restrict__ y, T* __restrict__ a, int lda, T* __restrict__ pooled,
+__global__ void bn_act_fwd_kernel(const T* __restrict__ y, int ldy, T* __restrict__ a, int lda,
+                                  T* __restrict__ pooled,
                                   unsigned char* __restrict__ argmax, int B, int H, int W, int C,
                                   const float* __restrict__ scale, const float* __restrict__ shift,
                                   const float* __restrict__ keep, int relu) {
@@ -161,7 +162,7 @@ __global__ void bn_act_fwd_kernel(const T* __restrict__ y, T* __restrict__ a, in
       const int yy = 2 * qy + dy, xx = 2 * qx + dx;
       if (yy < H && xx < W) {
         const long pix = ((long)b * H + yy) * W + xx;
-        Vec16<T> v = load16(y + pix * C + c0);
+        Vec16<T> v = load16(y + pix * ldy + c0);
         Vec16<T> o;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -746,7 +747,7 @@ int unetk_bn_fold_eval(const float* gamma, const float* beta, const float* runni
   return UNETK_OK;
 }
 
-int unetk_bn_act_fwd(const void* y, void* a, int lda, void* pooled, unsigned char* argmax, int B, int H, int W,
+int unetk_bn_act_fwd(const void* y, int ldy, void* a, int lda, void* pooled, unsigned char* argmax, int B, int H, int W,
                      int C, const float* scale, const float* shift, const float* keep, int relu, int dtype,
                      hipStream_t stream) {
   UNETK_CHECK_ARG(y && (a || pooled), "bn_act_fwd: null pointer");
@@ -754,11 +755,12 @@ int unetk_bn_act_fwd(const void* y, void* a, int lda, void* pooled, unsigned cha
   CHECK_DTYPE("bn_act_fwd", dtype);
   CHECK_VEC("bn_act_fwd", dtype, C);
   const int E = dtype == UNETK_BF16 ? 8 : 4;
+  UNETK_CHECK_ARG(ldy >= C && ldy % E == 0 && ((uintptr_t)y % 16) == 0, "bn_act_fwd: input stride %d", ldy);
   UNETK_CHECK_ARG(a == nullptr || (lda >= C && lda % E == 0 && ((uintptr_t)a % 16) == 0),
                   "bn_act_fwd: output stride %d (>= C, multiple of %d, 16-byte aligned base)", lda, E);
   const long total = (long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / E);
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3(cdiv(total, 256)), dim3(256), 0, stream,
-                                       (const T*)y, (T*)a, lda, (T*)pooled, argmax, B, H, W, C, scale, shift,
+                                       (const T*)y, ldy, (T*)a, lda, (T*)pooled, argmax, B, H, W, C, scale, shift,
                                        keep, relu));
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;

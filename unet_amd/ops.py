@@ -163,7 +163,7 @@ def bn_act_fwd(y, scale, shift, keep=None, relu=True, pool=False, write_a=True, 
     a = out if out is not None else (torch.empty_like(y) if write_a else None)
     pooled = torch.empty((B, H // 2, W // 2, C), dtype=y.dtype, device=y.device) if pool else None
     argmax = torch.empty((B, H // 2, W // 2, C), dtype=torch.uint8, device=y.device) if (pool and want_argmax) else None
-    call("unetk_bn_act_fwd", ptr(y), ptr(a), a.stride(2) if a is not None else 0, ptr(pooled), ptr(argmax),
+    call("unetk_bn_act_fwd", ptr(y), y.stride(2), ptr(a), a.stride(2) if a is not None else 0, ptr(pooled), ptr(argmax),
          B, H, W, C, ptr(scale), ptr(shift), ptr(keep), 1 if relu else 0, dtype_code(y.dtype), stream())
     if want_argmax:
         return a, pooled, argmax

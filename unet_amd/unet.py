@@ -143,20 +143,30 @@ class EvalEngine:
         self.head_w = model.conv.weight.detach()
         self.head_b = model.conv.bias.detach() if model.conv.bias is not None else None
 
-    def _block(self, name, t):
+    def _block(self, name, t, out=None):
         for ci in (0, 3):
             sc, sh = self.fold[(name, ci)]
-            t, _ = ops.conv_fwd(t, self.pk[(name, ci)], scale=sc, shift=sh, act=1)
+            t, _ = ops.conv_fwd(t, self.pk[(name, ci)], scale=sc, shift=sh, act=1, out=out if ci == 3 else None)
         return t
 
+    def _encoder(self, name, dec, t):
+        """An encoder block writes straight into the skip half of its decoder's concat buffer."""
+        seq, dseq = getattr(self.model, name), getattr(self.model, dec)
+        C2 = seq[3].out_channels
+        C1 = dseq[0].in_channels - C2
+        B, H, W, _ = t.shape
+        cat = torch.empty((B, H, W, C1 + C2), dtype=t.dtype, device=t.device)
+        e = self._block(name, t, out=cat[..., C1:])
+        return cat, ops.maxpool2x2(e)
+
     def __call__(self, h):
-        e1 = self._block("encoder1", h)
-        e2 = self._block("encoder2", ops.maxpool2x2(e1))
-        e3 = self._block("encoder3", ops.maxpool2x2(e2))
-        e4 = self._block("encoder4", ops.maxpool2x2(e3))
-        d = self._block("bottleneck", ops.maxpool2x2(e4))
-        for name, skip in (("decoder4", e4), ("decoder3", e3), ("decoder2", e2), ("decoder1", e1)):
-            d = self._block(name, ops.upsample_concat(d, skip))
+        cat1, p = self._encoder("encoder1", "decoder1", h)
+        cat2, p = self._encoder("encoder2", "decoder2", p)
+        cat3, p = self._encoder("encoder3", "decoder3", p)
+        cat4, p = self._encoder("encoder4", "decoder4", p)
+        d = self._block("bottleneck", p)
+        for name, cat in (("decoder4", cat4), ("decoder3", cat3), ("decoder2", cat2), ("decoder1", cat1)):
+            d = self._block(name, ops.upsample_into(d, cat))
         return ops.head1x1_fwd(d, self.head_w, self.head_b)
 
 
