@@ -1,0 +1,19 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence kept under profiles/ (run on the GPU box from the repo root):
+#   kernel-trace stats of the default bench command, and separate --pmc passes for HBM traffic
+#   (FETCH_SIZE, WRITE_SIZE) and MFMA busy cycles, for the train / predict / swin workloads.
+set -e
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/${1:-prof}
+mkdir -p $O
+cd /tmp; export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_trace -- python3 $R/bench.py --steps 10 --warmup 3 > $O/train_bench.log 2>&1
+for w in train predict swin; do
+  extra="--steps 2 --warmup 1 --no-cpu-baseline --no-roofline"
+  [ $w = predict ] && extra="--steps 1 --warmup 0 --no-cpu-baseline --grid 4096"
+  [ $w = swin ] && extra="--steps 2 --warmup 1 --batch 16"
+  timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${w}_fetch -- python3 $R/bench.py --workload $w $extra > $O/${w}_fetch.log 2>&1
+  timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${w}_write -- python3 $R/bench.py --workload $w $extra > $O/${w}_write.log 2>&1
+  timeout -s KILL 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/${w}_mfma -- python3 $R/bench.py --workload $w $extra > $O/${w}_mfma.log 2>&1
+done
+echo collected
