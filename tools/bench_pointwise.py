@@ -39,6 +39,8 @@ for hw, C in levels:
     res["pool_bwd"] = (timeit(lambda: ops.pool_bwd(a, dp, dskip)), 3.25 * S)
     low = torch.randn(B, hw // 2, hw // 2, 2 * C, device="cuda").to(dt)
     res["upsample_concat"] = (timeit(lambda: ops.upsample_concat(low, a)), (0.5 + 1 + 3) * S)
+    cat = torch.empty(B, hw, hw, 3 * C, device="cuda", dtype=dt)
+    res["upsample_into"] = (timeit(lambda: ops.upsample_into(low, cat)), (0.5 + 2) * S)
     res["upsample_bwd"] = (timeit(lambda: ops.upsample_bwd(dup, 2 * C, hw // 2, hw // 2)), 2.5 * S)
     line = f"{hw:4d}^2 C={C:4d} S={S*1e3:6.0f} MB |"
     for k, (t, gb) in res.items():

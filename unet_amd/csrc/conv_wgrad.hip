@@ -61,6 +61,22 @@ template <int ROW_BYTES> __device__ __forceinline__ int hswz(int row, int slot16
   return slot16;
 }
 
+// LDS image of the bf16 dy tile.  A transposing read touches, per 32-lane half, tile pixels
+// {o..o+3, o+8..o+11} at one 32-byte column unit.  With 96-byte rows (48 channels) pixels p and p+8
+// are 768 bytes = 3 bank rows apart and would collide whatever the slot order, so the pixels of a
+// 16-pixel block are stored interleaved (0,8,1,9,...): the eight rows of a read are then
+// consecutive and cover all 64 banks exactly once.  64- and 128-byte rows take the slot swizzle
+// of the halo instead.
+template <int ROW_BYTES> __device__ __forceinline__ int dy_row(int pix) {
+  return ROW_BYTES == 96 ? ((pix & ~15) | ((pix & 7) << 1) | ((pix >> 3) & 1)) : pix;
+}
+template <int ROW_BYTES> __device__ __forceinline__ int dy_pix(int row) {   // inverse of dy_row
+  return ROW_BYTES == 96 ? ((row & ~15) | ((row >> 1) & 7) | ((row & 1) << 3)) : row;
+}
+template <int ROW_BYTES> __device__ __forceinline__ int dy_slot(int pix, int slot16) {
+  return ROW_BYTES == 96 ? slot16 : hswz<ROW_BYTES>(pix, slot16);
+}
+
 template <typename T, int MT, int TW, int KS, int NWN>
 __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
   constexpr bool BF = sizeof(T) == 2;
@@ -74,7 +90,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
   constexpr int HW_ = (KS == 3) ? TW + 2 : TW;  // halo width
   constexpr int HH_ = (KS == 3) ? TR + 2 : TR;
   constexpr int HPIX = HH_ * HW_;
-  constexpr int RBD = BM * (int)sizeof(T);      // dy row bytes (96 B for 48 bf16 channels: conflict-free as is)
+  constexpr int RBD = BM * (int)sizeof(T);      // dy row bytes (LDS image: see dy_row / dy_slot)
   constexpr int RBH = KCI * (int)sizeof(T);     // halo row bytes
   constexpr int PPD = RBD / 16, PPH = RBH / 16;
   constexpr int DINSTR = (TPIX * PPD + 63) / 64, HINSTR = (HPIX * PPH + 63) / 64;
@@ -134,7 +150,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
       int i = wave + 8 * k;
       if (i >= DINSTR) i = DINSTR - 1;
       const int part = i * 64 + lane;
-      const int pix = part / PPD, slot = part - pix * PPD;
+      const int row = part / PPD, rslot = part - row * PPD;        // position in the LDS image
+      const int pix = BF ? dy_pix<RBD>(row) : row;
+      const int slot = BF ? dy_slot<RBD>(pix, rslot) : rslot;
       const int tr = pix / TW, tc = pix - tr * TW;
       const int gy = y0 + tr, gx = x0 + tc;
       const int c = co0 + slot * EPP;
@@ -170,8 +188,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
         bf16x8 af[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
-          af[m] = tr_read8(lds_dy + pk0 * RBD + (m * 16 + 4 * p4) * 2,
-                           lds_dy + pk1 * RBD + (m * 16 + 4 * p4) * 2);
+          af[m] = tr_read8(lds_dy + dy_row<RBD>(pk0) * RBD + dy_slot<RBD>(pk0, 2 * m + (p4 >> 1)) * 16 + (p4 & 1) * 8,
+                           lds_dy + dy_row<RBD>(pk1) * RBD + dy_slot<RBD>(pk1, 2 * m + (p4 >> 1)) * 16 + (p4 & 1) * 8);
         const int r0 = pk0 / TW, c0_ = pk0 - r0 * TW;
         const int slot = wn * 2 + (p4 >> 1), sub = (p4 & 1) * 8;
         // A lane's eight k-slots are eight consecutive pixels of one image row, so the three

@@ -131,11 +131,11 @@ __global__ void bn_act_fwd_kernel(const T* __restrict__ y, int ldy, T* __restric
   constexpr int E = Vec16<T>::N;
   const int CG = C / E;
   const int QH = (H + 1) >> 1, QW = (W + 1) >> 1;
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long total = (long)B * QH * QW * CG;
+  const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;     // the host checks that it fits 31 bits
+  const unsigned total = (unsigned)B * QH * QW * CG;
   if (idx >= total) return;
   const int cg = idx % CG;
-  long t = idx / CG;
+  unsigned t = idx / CG;
   const int qx = t % QW;
   t /= QW;
   const int qy = t % QH;
@@ -191,6 +191,47 @@ __global__ void bn_act_fwd_kernel(const T* __restrict__ y, int ldy, T* __restric
         *reinterpret_cast<unsigned int*>(argmax + q + e) =
             arg[e] | (arg[e + 1] << 8) | (arg[e + 2] << 16) | ((unsigned)arg[e + 3] << 24);
     }
+  }
+}
+
+// The same without pooling, as a stream: threads are (pixel lane, channel group), each keeps its
+// channel group's scale/shift in registers and walks the pixels of the workgroup's chunk, so every
+// wave instruction moves one contiguous kilobyte.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_stream_kernel(const T* __restrict__ y, int ldy, T* __restrict__ a,
+                                                            int lda, unsigned npix, unsigned hw, int C,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift,
+                                                            const float* __restrict__ keep, int relu,
+                                                            unsigned chunk) {
+  constexpr int E = Vec16<T>::N;
+  const int CG = C / E;
+  const int lanes = 256 / CG;
+  const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
+  if (pl >= lanes) return;
+  const int c0 = cg * E;
+  float sc[E], sh[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    sc[e] = scale ? scale[c0 + e] : 1.f;
+    sh[e] = shift ? shift[c0 + e] : 0.f;
+  }
+  const unsigned pbeg = blockIdx.x * chunk;
+  unsigned pend = pbeg + chunk;
+  if (pend > npix) pend = npix;
+  for (unsigned p = pbeg + pl; p < pend; p += lanes) {
+    Vec16<T> v = load16(y + (size_t)p * ldy + c0);
+    float kp[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) kp[e] = keep ? keep[(size_t)(p / hw) * C + c0 + e] : 1.f;
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      float z = to_f32(v.v[e]) * sc[e] + sh[e];
+      if (relu) z = fmaxf(z, 0.f);
+      o.v[e] = from_f32<T>(z * kp[e]);
+    }
+    store16(a + (size_t)p * lda + c0, o);
   }
 }
 
@@ -410,10 +451,10 @@ __global__ void pool_bwd_kernel(const T* __restrict__ a, const unsigned char* __
   constexpr int E = Vec16<T>::N;
   const int CG = C / E;
   const int QH = (H + 1) >> 1, QW = (W + 1) >> 1;
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)B * QH * QW * CG) return;
+  const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;     // the host checks that it fits 31 bits
+  if (idx >= (unsigned)B * QH * QW * CG) return;
   const int cg = idx % CG;
-  long t = idx / CG;
+  unsigned t = idx / CG;
   const int qx = t % QW;
   t /= QW;
   const int qy = t % QH;
@@ -503,13 +544,13 @@ __global__ void upsample_concat_kernel(const T* __restrict__ low, int h, int w, 
   constexpr int E = Vec16<T>::N;
   const int C = C1 + C2, CG1 = C1 / E;
   const int CG = skip != nullptr ? C / E : CG1;   // without a skip only channels [0,C1) are written
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)B * H * W * CG) return;
+  const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;     // the host checks that it fits 31 bits
+  if (idx >= (unsigned)B * H * W * CG) return;
   const int cg = idx % CG;
-  long p = idx / CG;
+  const unsigned p = idx / CG;
   const int x = p % W;
   const int y = (p / W) % H;
-  const int b = p / ((long)W * H);
+  const int b = p / ((unsigned)W * H);
   Vec16<T> o;
   if (cg < CG1) {
     int y0, y1, x0, x1;
@@ -528,9 +569,9 @@ __global__ void upsample_concat_kernel(const T* __restrict__ low, int h, int w, 
       o.v[e] = from_f32<T>(hy * (hx * to_f32(v00.v[e]) + lx * to_f32(v01.v[e])) +
                            ly * (hx * to_f32(v10.v[e]) + lx * to_f32(v11.v[e])));
   } else {
-    o = load16(skip + p * ldskip + (cg - CG1) * E);
+    o = load16(skip + (size_t)p * ldskip + (cg - CG1) * E);
   }
-  store16(out + p * C + cg * E, o);
+  store16(out + (size_t)p * C + cg * E, o);
 }
 
 // dlow[b,i,j,:] = sum over output pixels (y,x) that read (i,j) of wy*wx*dout[b,y,x,:] (gather form)
@@ -541,13 +582,13 @@ __global__ void upsample_bwd_kernel(const T* __restrict__ dout, int ldout, int H
   const int CG = C1 / E;
   // Neighbouring low-resolution rows gather from overlapping rows of dout: each XCD (workgroups
   // are dealt to them round-robin) takes a contiguous range of blocks so the overlap stays in its L2.
-  const long idx = xcd_contiguous_block() * blockDim.x + threadIdx.x;
-  if (idx >= (long)B * h * w * CG) return;
+  const unsigned idx = (unsigned)xcd_contiguous_block() * blockDim.x + threadIdx.x;   // fits 31 bits (host check)
+  if (idx >= (unsigned)B * h * w * CG) return;
   const int cg = idx % CG;
-  long p = idx / CG;
+  const unsigned p = idx / CG;
   const int j = p % w;
   const int i = (p / w) % h;
-  const int b = p / ((long)w * h);
+  const int b = p / ((unsigned)w * h);
   float acc[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) acc[e] = 0.f;
@@ -612,7 +653,7 @@ __global__ void upsample_bwd_kernel(const T* __restrict__ dout, int ldout, int H
   Vec16<T> o;
 #pragma unroll
   for (int e = 0; e < E; ++e) o.v[e] = from_f32<T>(acc[e]);
-  store16(dlow + p * C1 + cg * E, o);
+  store16(dlow + (size_t)p * C1 + cg * E, o);
 }
 
 // ------------------------------------------------------------------ final 1x1 convolution (few outputs)
@@ -758,7 +799,21 @@ int unetk_bn_act_fwd(const void* y, int ldy, void* a, int lda, void* pooled, uns
   UNETK_CHECK_ARG(ldy >= C && ldy % E == 0 && ((uintptr_t)y % 16) == 0, "bn_act_fwd: input stride %d", ldy);
   UNETK_CHECK_ARG(a == nullptr || (lda >= C && lda % E == 0 && ((uintptr_t)a % 16) == 0),
                   "bn_act_fwd: output stride %d (>= C, multiple of %d, 16-byte aligned base)", lda, E);
+  const long npix = (long)B * H * W;
+  if (pooled == nullptr && C / E <= 256 && npix < (1L << 31)) {
+    const int lanes = 256 / (C / E);
+    long nb = (npix + (long)lanes * 8 - 1) / ((long)lanes * 8);
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    const unsigned chunk = (unsigned)((npix + nb - 1) / nb);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_stream_kernel<T>, dim3((unsigned)cdiv(npix, chunk)), dim3(256), 0,
+                                         stream, (const T*)y, ldy, (T*)a, lda, (unsigned)npix,
+                                         (unsigned)((long)H * W), C, scale, shift, keep, relu, chunk));
+    UNETK_CHECK_LAUNCH();
+    return UNETK_OK;
+  }
   const long total = (long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / E);
+  UNETK_CHECK_ARG(total < (1L << 31), "bn_act_fwd: tensor too large");
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3(cdiv(total, 256)), dim3(256), 0, stream,
                                        (const T*)y, ldy, (T*)a, lda, (T*)pooled, argmax, B, H, W, C, scale, shift,
                                        keep, relu));
@@ -824,6 +879,7 @@ int unetk_pool_bwd(const void* a, const unsigned char* argmax, const void* dpool
   const int E = dtype == UNETK_BF16 ? 8 : 4;
   UNETK_CHECK_ARG(dskip == nullptr || ldskip % E == 0, "pool_bwd: skip stride misaligned");
   const long total = (long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / E);
+  UNETK_CHECK_ARG(total < (1L << 31), "pool_bwd: tensor too large");
   DISPATCH_T(dtype, hipLaunchKernelGGL(pool_bwd_kernel<T>, dim3(cdiv(total, 256)), dim3(256), 0, stream,
                                        (const T*)a, argmax, (const T*)dpooled, (const T*)dskip, ldskip,
                                        (T*)da, B, H, W, C));
@@ -840,6 +896,7 @@ int unetk_upsample_concat_fwd(const void* low, int h, int w, int C1, const void*
   const int E = dtype == UNETK_BF16 ? 8 : 4;
   const float sy = (float)h / (float)H, sx = (float)w / (float)W;
   const long total = (long)B * H * W * ((skip ? C1 + C2 : C1) / E);
+  UNETK_CHECK_ARG(total < (1L << 31), "upsample_concat_fwd: tensor too large");
   DISPATCH_T(dtype, hipLaunchKernelGGL(upsample_concat_kernel<T>, dim3(cdiv(total, 256)), dim3(256), 0,
                                        stream, (const T*)low, h, w, C1, (const T*)skip, ldskip, C2, (T*)out,
                                        B, H, W, sy, sx));
@@ -856,6 +913,7 @@ int unetk_upsample_bwd(const void* dout, int ldout, int H, int W, void* dlow, in
   UNETK_CHECK_ARG(ldout % E == 0, "upsample_bwd: stride misaligned");
   const float sy = (float)h / (float)H, sx = (float)w / (float)W;
   const long total = (long)B * h * w * (C1 / E);
+  UNETK_CHECK_ARG(total < (1L << 31), "upsample_bwd: tensor too large");
   DISPATCH_T(dtype, hipLaunchKernelGGL(upsample_bwd_kernel<T>, dim3(8 * cdiv(cdiv(total, 256), 8)), dim3(256), 0, stream,
                                        (const T*)dout, ldout, H, W, (T*)dlow, B, h, w, C1, sy, sx));
   UNETK_CHECK_LAUNCH();
