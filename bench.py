@@ -5,8 +5,8 @@
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 One step = one pass of the hot path over one synthetic batch that is already resident in HBM:
-OptimizedUNet(4,1,48) forward, the 'all' multi-loss, backward to every parameter (and, for N > 1,
-the data-parallel gradient all-reduce over RCCL).  Workload = BASELINE config 2: batch 64 of
+OptimizedUNet(4,1,48) forward, the 'all' multi-loss, backward to every parameter (for N > 1 the
+data-parallel gradient all-reduce over RCCL), global-norm clip and the AdamW update.  Workload = BASELINE config 2: batch 64 of
 4x256x256 patches per GPU, bf16 storage with fp32 accumulation.  Rank 0 prints ONE JSON line.
 
 The line also carries
@@ -292,11 +292,15 @@ def main():
     if world > 1:
         from unet_amd.dist import GradReducer
         reducer = GradReducer(model)
+    # the trainer's optimizer tail (enhanced_training_multi_loss.py:758-763, 827-829)
+    from unet_amd.optim import FusedAdamW
+    opt = FusedAdamW(model.parameters(), lr=5e-5, weight_decay=5e-5, max_grad_norm=1.0)
 
     def step():
         loss = train_step(model, crit, x, y, w)
         if reducer is not None:
             reducer.allreduce()
+        opt.step()
         return loss
 
     for _ in range(args.warmup):
@@ -337,7 +341,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"UNet(4,1,48) training step fwd+loss({loss_name})+bwd, batch {args.batch}/GPU of "
+            "config": {"workload": f"UNet(4,1,48) training step fwd+loss({loss_name})+bwd+clip+AdamW, batch {args.batch}/GPU of "
                                    f"4x{args.size}x{args.size}, {args.dtype} storage fp32 accumulate",
                        "global_batch": world * args.batch, "patch": args.size,
                        "parallelism": f"dp{world}" if world > 1 else "single"},

@@ -204,6 +204,25 @@ int unetk_window_attn_bwd(const void* qkv, const void* dout, void* dqkv, const f
                           float* dtable_partials, int B, int He, int We, int C, int heads, int shift, int use_mask,
                           float scale, int dtype, unetk_stream_t stream);
 
+/* ---- optimizer tail: clip_grad_norm_ + AdamW over a list of fp32 tensors ----------------
+ * enhanced_training_multi_loss.py:758-763 (AdamW), :827-829 (clip_grad_norm_(1.0), step);
+ * swin_unet_model.py:836-842.  Tensors are given as device arrays of pointers + sizes; `chunks`
+ * is a device table of (tensor index, chunk index) pairs, one per workgroup, chunk =
+ * unetk_optim_chunk_elems() elements.  unetk_grad_norm writes out[0] = global L2 norm and
+ * out[1] = min(1, max_norm / (norm + 1e-6)) (partials: nchunks floats of scratch).
+ * unetk_adamw_step applies torch.optim.AdamW's update for step number `step` (1-based); with
+ * clip_coef (device pointer, nullable) the gradients are scaled by it first (and written back
+ * when write_grad != 0). */
+int unetk_optim_chunk_elems(void);
+int unetk_grad_norm(const float* const* grads, const int64_t* sizes, const int32_t* chunks, int nchunks,
+                    float max_norm, float* partials, float* out, unetk_stream_t stream);
+int unetk_scale_list(float* const* tensors, const int64_t* sizes, const int32_t* chunks, int nchunks,
+                     const float* coef, unetk_stream_t stream);
+int unetk_adamw_step(float* const* params, float* const* grads, float* const* m, float* const* v,
+                     const int64_t* sizes, const int32_t* chunks, int nchunks, double lr, double beta1,
+                     double beta2, double eps, double weight_decay, int64_t step, const float* clip_coef,
+                     int write_grad, unetk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

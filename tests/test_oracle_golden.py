@@ -158,3 +158,22 @@ def test_swin_oracle_matches_golden(golden, name, B, H, Wd):
     norms = np.array([params[k].grad.norm().item() for k in names])
     keep = np.array([k != "final_conv.0.bias" for k in names])
     assert rel(norms[keep], g[f"{name}.grad_norms"][keep]) < 1e-8
+
+
+def test_training_step_oracle_matches_golden(golden):
+    """loss -> backward -> clip_grad_norm_(1.0) -> AdamW as the reference trainer does it."""
+    from oracle import step_oracle
+    g = golden("step")
+    cin, f, B, H, Wd = 4, 8, 2, 32, 32
+    sd = W.fill_state_dict(W.unet_template(cin, 1, f), seed=42)
+    x, y, w = W.synthetic_batch(B, cin, H, Wd, seed=42)
+    parts, norm, new = step_oracle.training_step(sd, x, y, w, loss_oracle.preset("all"))
+    want = g["parts"]
+    got = np.array([parts[k] for k in ("pixel", "gradient", "spectral", "total")])
+    assert rel(got, want) < 1e-5
+    assert abs(norm - float(g["grad_norm"])) < 1e-4 * float(g["grad_norm"])
+    names = [str(s) for s in g["param_names"]]
+    delta = np.array([(new[k] - sd[k]).double().norm().item() for k in names])
+    assert rel(delta, g["param_delta_norms"]) < 1e-3
+    heads = np.concatenate([sub(new[k], 8) for k in names])
+    assert rel(heads, g["param_heads"]) < 1e-6

@@ -3,3 +3,4 @@ from .unet import OptimizedUNet  # noqa: F401
 from .losses import MultiLossFunction, TIDWeightedLoss, GradientLoss, SpectralLoss  # noqa: F401
 from .swin import SwinUNet  # noqa: F401
 from .predictor import LargeAreaPredictor, LargeAreaPredictionConfig  # noqa: F401
+from .optim import FusedAdamW, clip_grad_norm_  # noqa: F401

@@ -5,7 +5,7 @@ streams come from torch; the kernels take raw device pointers.
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 
 import torch
 
@@ -25,7 +25,7 @@ class UnetkMissing(ImportError):
     pass
 
 
-P, I, L, F = c_void_p, c_int, c_int64, c_float
+P, I, L, F, D = c_void_p, c_int, c_int64, c_float, c_double
 
 # name -> (restype, argtypes); mirrors include/unetk.h one to one
 _SIGNATURES = {
@@ -39,6 +39,10 @@ _SIGNATURES = {
     "unetk_conv_fwd_split": (I, [P, I, P, P, I, P, I, I, I, I, I, I, I, I, I, I, P, P, P, I, P, I, P, P]),
     "unetk_conv_wgrad_workspace_bytes": (L, [I, I, I, I, I, I, I]),
     "unetk_conv_wgrad": (I, [P, I, P, I, P, I, I, I, I, I, I, I, P, L, I, P]),
+    "unetk_optim_chunk_elems": (I, []),
+    "unetk_grad_norm": (I, [P, P, P, I, F, P, P, P]),
+    "unetk_scale_list": (I, [P, P, P, I, P, P]),
+    "unetk_adamw_step": (I, [P, P, P, P, P, P, I, D, D, D, D, D, L, P, I, P]),
     "unetk_nchw_to_nhwc": (I, [P, P, I, I, I, I, I, I, P]),
     "unetk_nhwc_to_nchw": (I, [P, I, P, I, I, I, I, I, P]),
     "unetk_bn_finalize": (I, [P, I, I, L, P, P, F, F, P, P, P, P, P, P, P]),

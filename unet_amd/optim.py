@@ -1,0 +1,150 @@
+"""Optimizer tail of the training step on the GPU: global-norm gradient clipping and AdamW.
+
+Drop-ins for the two calls the reference trainers make after ``loss.backward()``
+(enhanced_training_multi_loss.py:827-829, swin_unet_model.py:836-842):
+
+    torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)   ->  clip_grad_norm_(...)
+    torch.optim.AdamW(model.parameters(), lr=..., weight_decay=...)     ->  FusedAdamW(...)
+
+Both walk the whole parameter list in one kernel launch each (device arrays of pointers and a
+chunk table), instead of one small launch per tensor.  ``FusedAdamW(max_grad_norm=1.0)`` fuses
+the two: the norm kernel leaves the clip coefficient on the device and the update applies it
+while it reads the gradients.  State keys (``step``, ``exp_avg``, ``exp_avg_sq``) are torch's, so
+optimizer checkpoints interchange.  GPU tensors only.
+"""
+from typing import Iterable, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream
+
+
+class _TensorList:
+    """Device-side description of a list of fp32 tensors: pointer array, sizes, chunk table."""
+
+    def __init__(self, tensors: List[torch.Tensor]):
+        if not tensors:
+            raise ValueError("empty tensor list")
+        dev = tensors[0].device
+        for t in tensors:
+            if t.device != dev or t.dtype != torch.float32 or not t.is_cuda:
+                raise RuntimeError("fused optimizer kernels take float32 CUDA tensors on one device")
+            if not t.is_contiguous():
+                raise RuntimeError("fused optimizer kernels take contiguous tensors")
+        self.device = dev
+        self.sizes_h = [t.numel() for t in tensors]
+        chunk = _lib.load().unetk_optim_chunk_elems()
+        table = [(i, c) for i, n in enumerate(self.sizes_h) for c in range((n + chunk - 1) // chunk)]
+        self.nchunks = len(table)
+        self.sizes = torch.tensor(self.sizes_h, dtype=torch.int64, device=dev)
+        self.chunks = torch.tensor(np.asarray(table, dtype=np.int32).reshape(-1), dtype=torch.int32, device=dev)
+        self.partials = torch.empty(self.nchunks, dtype=torch.float32, device=dev)
+
+        self._tables = {}
+
+    def pointers(self, tensors: List[torch.Tensor], slot: str = "") -> torch.Tensor:
+        """Device array of the tensors' addresses.  The last table of each slot is kept (parameters
+        and moments never move; re-allocated gradients usually come back at the same addresses);
+        a changed table goes up from pinned memory without blocking the host, so the launch queue
+        never drains."""
+        key = tuple(t.data_ptr() for t in tensors)
+        hit = self._tables.get(slot)
+        if hit is None or hit[0] != key:
+            host = torch.tensor(key, dtype=torch.int64).pin_memory()
+            hit = (key, host.to(self.device, non_blocking=True), host)
+            self._tables[slot] = hit
+        return hit[1]
+
+
+def _grads_of(params: List[torch.Tensor]) -> List[torch.Tensor]:
+    return [p.grad for p in params]
+
+
+def clip_grad_norm_(parameters: Iterable[torch.Tensor], max_norm: float, norm_type: float = 2.0) -> torch.Tensor:
+    """In-place global-norm clip; returns the total norm (0-dim tensor on the device)."""
+    if float(norm_type) != 2.0:
+        raise ValueError("only the L2 norm is implemented (the reference uses the default)")
+    if isinstance(parameters, torch.Tensor):
+        parameters = [parameters]
+    params = [p for p in parameters if p.grad is not None]
+    if not params:
+        return torch.zeros(())
+    grads = _grads_of(params)
+    tl = _TensorList(grads)
+    gp = tl.pointers(grads, "g")
+    out = torch.empty(2, dtype=torch.float32, device=tl.device)
+    call("unetk_grad_norm", ptr(gp), ptr(tl.sizes), ptr(tl.chunks), tl.nchunks, float(max_norm), ptr(tl.partials),
+         ptr(out), stream())
+    call("unetk_scale_list", ptr(gp), ptr(tl.sizes), ptr(tl.chunks), tl.nchunks, ptr(out[1:]), stream())
+    return out[0]
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW semantics (decoupled weight decay, bias correction), one launch per group.
+
+    ``max_grad_norm`` (optional) fuses ``clip_grad_norm_`` over ALL parameters of the optimizer
+    into the step; the norm of the last step is kept in ``last_grad_norm`` (device tensor).
+    """
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
+                 max_grad_norm: Optional[float] = None):
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
+            raise ValueError("invalid AdamW hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.max_grad_norm = max_grad_norm
+        self.last_grad_norm = None
+        self._lists = {}
+
+    def _list_for(self, key, tensors):
+        sig = tuple(t.numel() for t in tensors)
+        hit = self._lists.get(key)
+        if hit is None or hit[0] != sig:
+            hit = (sig, _TensorList(tensors))
+            self._lists[key] = hit
+        return hit[1]
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        coef = None
+        if self.max_grad_norm is not None:
+            allp = [p for g in self.param_groups for p in g["params"] if p.grad is not None]
+            if allp:
+                grads = _grads_of(allp)
+                tl = self._list_for("norm", grads)
+                out = torch.empty(2, dtype=torch.float32, device=tl.device)
+                gp = tl.pointers(grads, "g")
+                call("unetk_grad_norm", ptr(gp), ptr(tl.sizes), ptr(tl.chunks), tl.nchunks,
+                     float(self.max_grad_norm), ptr(tl.partials), ptr(out), stream())
+                self.last_grad_norm = out[0]
+                coef = out[1:]
+        for gi, group in enumerate(self.param_groups):
+            params = [p for p in group["params"] if p.grad is not None]
+            if not params:
+                continue
+            for p in params:
+                st = self.state[p]
+                if not st:
+                    st["step"] = torch.zeros((), dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            steps = {int(self.state[p]["step"]) for p in params}
+            if len(steps) != 1:
+                raise RuntimeError("parameters of one group must share their step count")
+            step = steps.pop() + 1
+            for p in params:
+                self.state[p]["step"] += 1
+            tl = self._list_for(gi, params)
+            grads = _grads_of(params)
+            b1, b2 = group["betas"]
+            pp, gp = tl.pointers(params, "p"), tl.pointers(grads, "g")
+            mp = tl.pointers([self.state[p]["exp_avg"] for p in params], "m")
+            vp = tl.pointers([self.state[p]["exp_avg_sq"] for p in params], "v")
+            call("unetk_adamw_step", ptr(pp), ptr(gp), ptr(mp), ptr(vp), ptr(tl.sizes), ptr(tl.chunks), tl.nchunks, float(group["lr"]), float(b1), float(b2),
+                 float(group["eps"]), float(group["weight_decay"]), step, ptr(coef), 1, stream())
+        return loss
