@@ -94,3 +94,25 @@ def test_full_size_linearity_property():
     o, parts = loss_oracle.multi_loss(cfg, p[:2].cpu(), y[:2], w[:2])
     t, gp = crit(p[:2], yd[:2], wd[:2])
     assert abs(t.item() - o.item()) < 1e-4 * abs(o.item())
+
+
+def test_loss_parts_behave_like_the_reference_dict():
+    """The parts dict fetches its floats lazily but reads like a plain dict of floats."""
+    import json
+    import pickle
+    from unet_amd.losses import MultiLossFunction
+    x, y, w = W.synthetic_batch(2, 1, 16, 16, seed=3)
+    crit = MultiLossFunction(loss_oracle.preset("all")).cuda()
+    total, parts = crit(x.cuda(), y.cuda(), w.cuda())
+    assert isinstance(parts, dict) and set(parts) == {"pixel", "gradient", "spectral", "total"}
+    plain = dict(parts)
+    assert all(isinstance(v, float) for v in plain.values())
+    assert abs(plain["total"] - total.item()) < 1e-6 * max(1.0, abs(total.item()))
+    _, again = crit(x.cuda(), y.cuda(), w.cuda())
+    assert again == plain and {**again} == plain and json.loads(json.dumps(again)) == plain
+    assert pickle.loads(pickle.dumps(again)) == plain and again.copy() == plain and again.get("pixel") == plain["pixel"]
+    acc = {k: 0.0 for k in plain}
+    _, third = crit(x.cuda(), y.cuda(), w.cuda())
+    for k, v in third.items():      # the trainer's accumulation loop
+        acc[k] += v
+    assert acc == plain

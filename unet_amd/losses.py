@@ -148,6 +148,65 @@ class SpectralLoss(nn.Module):
         return total
 
 
+class _LossParts(dict):
+    """The reference's ``{'pixel', 'gradient', 'spectral', 'total': float}`` dict, with the one
+    device-to-host copy deferred to the first read: a training loop that does not look at the
+    parts every step never synchronises the host with the GPU."""
+
+    def __init__(self, res: torch.Tensor, use_grad: bool, use_spec: bool):
+        super().__init__(pixel=None, gradient=None, spectral=None, total=None)
+        self._pending = (res, use_grad, use_spec)
+
+    def _fetch(self):
+        if self._pending is not None:
+            res, use_grad, use_spec = self._pending
+            self._pending = None
+            vals = res[:4].tolist()
+            dict.update(self, pixel=vals[0], gradient=vals[1] if use_grad else 0.0,
+                        spectral=vals[2] if use_spec else 0.0, total=vals[3])
+
+    def __getitem__(self, key):
+        self._fetch()
+        return dict.__getitem__(self, key)
+
+    def __iter__(self):            # (also keeps dict(parts) and {**parts} off the raw-storage fast path)
+        self._fetch()
+        return dict.__iter__(self)
+
+    def get(self, key, default=None):
+        self._fetch()
+        return dict.get(self, key, default)
+
+    def items(self):
+        self._fetch()
+        return dict.items(self)
+
+    def values(self):
+        self._fetch()
+        return dict.values(self)
+
+    def copy(self):
+        self._fetch()
+        return dict(dict.items(self))
+
+    def __eq__(self, other):
+        self._fetch()
+        return dict.__eq__(self, other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = None
+
+    def __repr__(self):
+        self._fetch()
+        return dict.__repr__(self)
+
+    def __reduce__(self):
+        self._fetch()
+        return (dict, (dict(dict.items(self)),))
+
+
 class MultiLossFunction(nn.Module):
     """reference enhanced_training_multi_loss.py:347-416"""
 
@@ -179,7 +238,4 @@ class MultiLossFunction(nn.Module):
                    w_grad=self.gradient_weight, w_spec=self.spectral_weight, use_grad=use_grad,
                    use_spec=use_spec)
         total, res = _run(pred, target, tid_weights, cfg)
-        vals = res[:4].tolist()          # the one device-to-host copy of the step
-        losses = {"pixel": vals[0], "gradient": vals[1] if use_grad else 0.0,
-                  "spectral": vals[2] if use_spec else 0.0, "total": vals[3]}
-        return total, losses
+        return total, _LossParts(res, use_grad, use_spec)

@@ -181,6 +181,10 @@ class _UNetTrainFn(torch.autograd.Function):
     def forward(ctx, x, model, masks, *params):
         dt = model.compute_dtype
         pk = _pack_all(model, dt, False)
+        # The data-gradient packs are queued now as well: the loss usually synchronises the host
+        # (its parts are Python floats), and 18 small launches right after that would run with the
+        # GPU idle in between.
+        ctx.pkT = _pack_all(model, dt, True)
         saved = {}
         B = x.shape[0]
         h = ops.nchw_to_nhwc(x.detach(), dt)
@@ -242,7 +246,8 @@ class _UNetTrainFn(torch.autograd.Function):
     def backward(ctx, dout):
         model, saved = ctx.model, ctx.saved
         dt = model.compute_dtype
-        pkT = _pack_all(model, dt, True)
+        pkT = ctx.pkT
+        ctx.pkT = None
         grads = {}
         # Weight gradients are off the critical chain (dgrad -> BatchNorm backward -> dgrad ...):
         # optionally they run on a second HIP stream, overlapping the HBM-bound BatchNorm / pool /
