@@ -223,6 +223,19 @@ int unetk_adamw_step(float* const* params, float* const* grads, float* const* m,
                      double beta2, double eps, double weight_decay, int64_t step, const float* clip_coef,
                      int write_grad, unetk_stream_t stream);
 
+/* ---- training-patch extraction -------------------------------------------------------
+ * EnhancedDataPreparation.extract_patches, enhanced_training_multi_loss.py:633-720: candidate
+ * windows start at margin + k*S (margin = P/8) while start + P + margin <= size, row-major.
+ * unetk_patch_qc writes flags[candidate] = 1 when the window passes the quality rules (:666-701).
+ * unetk_patch_gather copies the windows at pos[k] = (lat_start, lon_start) into (n, nvar, P, P),
+ * (n, 1, P, P), (n, 1, P, P); sanitize != 0 replaces NaN/inf by 0 and flips[k] in {0, 1 = last
+ * axis reversed, 2 = rows reversed} applies the dataset's augmentation (:425-450, :484-489). */
+int unetk_patch_qc(const float* feats, int nvar, const float* labels, const float* weights, int lat, int lon,
+                   int P, int S, double min_valid, int* flags, unetk_stream_t stream);
+int unetk_patch_gather(const float* feats, int nvar, const float* labels, const float* weights, int lat, int lon,
+                       const int* pos, const int* flips, int n, int P, int sanitize, float* out_f, float* out_l,
+                       float* out_w, unetk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,7 +26,7 @@ REF = "/root/reference"
 sys.path.insert(0, REPO)
 sys.dont_write_bytecode = True
 
-from oracle import loss_oracle, swin_oracle, tile_oracle, unet_oracle  # noqa: E402
+from oracle import loss_oracle, patch_oracle, swin_oracle, tile_oracle, unet_oracle  # noqa: E402
 from oracle import weights as W  # noqa: E402
 
 
@@ -377,10 +377,51 @@ def gen_step(etml):
     print("step.npz", len(out), "entries")
 
 
+PATCH_CASES = [("p16", 96, 112, 16, 8, 0.25, 21), ("p32", 160, 128, 32, 16, 0.25, 22), ("p8", 40, 33, 8, 3, 0.5, 23)]
+
+
+class _DA(_Var):
+    """Duck-typed xarray.DataArray: .lat, .lon, .isel(lat=, lon=).values"""
+    def __init__(self, a):
+        super().__init__(a)
+        self.lat, self.lon = np.arange(a.shape[0]), np.arange(a.shape[1])
+
+
+def gen_patch(etml):
+    """Training-patch extraction and sample preparation (enhanced_training_multi_loss.py:633-720, 470-513)."""
+    out = {}
+    for name, lat, lon, P, S, mv, seed in PATCH_CASES:
+        feats, labels, weights = patch_oracle.synthetic_fields(lat, lon, seed)
+        cfg = type("C", (), {"OUTPUT_DIR": tempfile.mkdtemp(), "PATCH_SIZE": P, "STRIDE": S, "MIN_VALID_RATIO": mv,
+                             "USE_DATA_AUGMENTATION": False, "AUGMENTATION_PROB": 0.0})
+        ref = etml.EnhancedDataPreparation(cfg).extract_patches(_DS(feats), _DA(labels), _DA(weights))
+        mine = patch_oracle.extract_patches(feats, labels, weights, P, S, mv)
+        assert len(ref) == len(mine) and len(ref) > 0, (name, len(ref), len(mine))
+        ncand = len(patch_oracle.candidate_starts(lat, P, S)) * len(patch_oracle.candidate_starts(lon, P, S))
+        assert len(ref) < ncand, f"{name}: every candidate passed, the rules are not exercised"
+        ds = etml.EnhancedBathymetryDataset(ref, cfg, is_training=False)
+        sums = []
+        for k, (a, b) in enumerate(zip(ref, mine)):
+            assert (a["lat_start"], a["lon_start"]) == (b["lat_start"], b["lon_start"])
+            for key in ("features", "label", "tid_weights"):
+                assert np.array_equal(a[key], b[key], equal_nan=True), (name, k, key)
+            f, l, w = ds[k]
+            fo, lo, wo = patch_oracle.dataset_item(b)
+            assert np.array_equal(f.numpy(), fo) and np.array_equal(l.numpy(), lo) and np.array_equal(w.numpy(), wo)
+            assert np.array_equal(torch.flip(f, dims=[2]).numpy(), patch_oracle.dataset_item(b, "h")[0])
+            assert np.array_equal(torch.flip(l, dims=[1]).numpy(), patch_oracle.dataset_item(b, "v")[1])
+            sums.append([fo.astype(np.float64).sum(), lo.astype(np.float64).sum(), wo.astype(np.float64).sum()])
+        out[name + ".pos"] = np.array([(p["lat_start"], p["lon_start"]) for p in ref], dtype=np.int32)
+        out[name + ".sums"] = np.array(sums)
+        out[name + ".ncand"] = np.int64(ncand)
+    np.savez_compressed(os.path.join(HERE, "patch.npz"), **out)
+    print("patch.npz", len(out), "entries")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     tr, etml, swin, lap = import_reference()
-    which = sys.argv[1:] or ["unet", "loss", "tile", "swin", "step"]
+    which = sys.argv[1:] or ["unet", "loss", "tile", "swin", "step", "patch"]
     if "unet" in which:
         gen_unet(tr)
     if "loss" in which:
@@ -391,3 +432,5 @@ if __name__ == "__main__":
         gen_swin(swin)
     if "step" in which:
         gen_step(etml)
+    if "patch" in which:
+        gen_patch(etml)

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import loss_oracle, swin_oracle, tile_oracle, unet_oracle
+from oracle import loss_oracle, patch_oracle, swin_oracle, tile_oracle, unet_oracle
 from oracle import weights as W
 
 
@@ -177,3 +177,34 @@ def test_training_step_oracle_matches_golden(golden):
     assert rel(delta, g["param_delta_norms"]) < 1e-3
     heads = np.concatenate([sub(new[k], 8) for k in names])
     assert rel(heads, g["param_heads"]) < 1e-6
+
+
+PATCH_CASES = [("p16", 96, 112, 16, 8, 0.25, 21), ("p32", 160, 128, 32, 16, 0.25, 22), ("p8", 40, 33, 8, 3, 0.5, 23)]
+
+
+class _DA:
+    """Duck-typed xarray.DataArray: .lat, .lon, .isel(lat=, lon=).values"""
+    def __init__(self, a):
+        self.a = a
+        self.lat, self.lon = np.arange(a.shape[0]), np.arange(a.shape[1])
+
+    def isel(self, lat, lon):
+        import types
+        return types.SimpleNamespace(values=self.a[lat, lon])
+
+
+class _DSet(dict):
+    def __init__(self, arrays):
+        super().__init__({k: _DA(v) for k, v in arrays.items()})
+
+
+@pytest.mark.parametrize("case", PATCH_CASES, ids=[c[0] for c in PATCH_CASES])
+def test_patch_oracle_matches_golden(golden, case):
+    name, lat, lon, P, S, mv, seed = case
+    g = golden("patch")
+    feats, labels, weights = patch_oracle.synthetic_fields(lat, lon, seed)
+    got = patch_oracle.extract_patches(feats, labels, weights, P, S, mv)
+    assert np.array_equal(np.array([(p["lat_start"], p["lon_start"]) for p in got], np.int32), g[name + ".pos"])
+    assert 0 < len(got) < int(g[name + ".ncand"])
+    sums = np.array([[a.astype(np.float64).sum() for a in patch_oracle.dataset_item(p)] for p in got])
+    assert np.array_equal(sums, g[name + ".sums"])
