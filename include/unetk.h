@@ -236,6 +236,15 @@ int unetk_patch_gather(const float* feats, int nvar, const float* labels, const 
                        const int* pos, const int* flips, int n, int P, int sanitize, float* out_f, float* out_l,
                        float* out_w, unetk_stream_t stream);
 
+/* ---- validation metrics as streaming reductions ---------------------------------------
+ * enhanced_training_multi_loss.py:883-889 (np.corrcoef over the concatenated validation set),
+ * predict.py:188-200 (MSE, MAE, Pearson r).  state: 8 doubles on the device, zeroed by the
+ * caller: count, sum p, sum t, sum p^2, sum t^2, sum p*t, sum |p-t|, sum (p-t)^2; each call adds a
+ * batch.  partials: unetk_metrics_num_partials(n) * 8 doubles of scratch. */
+int unetk_metrics_num_partials(int64_t n);
+int unetk_metrics_update(const float* pred, const float* target, int64_t n, double* partials, double* state,
+                         unetk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,3 +4,5 @@ from .losses import MultiLossFunction, TIDWeightedLoss, GradientLoss, SpectralLo
 from .swin import SwinUNet  # noqa: F401
 from .predictor import LargeAreaPredictor, LargeAreaPredictionConfig  # noqa: F401
 from .optim import FusedAdamW, clip_grad_norm_  # noqa: F401
+from .data import EnhancedDataPreparation  # noqa: F401
+from .metrics import StreamingMetrics  # noqa: F401

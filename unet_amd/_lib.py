@@ -45,6 +45,8 @@ _SIGNATURES = {
     "unetk_adamw_step": (I, [P, P, P, P, P, P, I, D, D, D, D, D, L, P, I, P]),
     "unetk_patch_qc": (I, [P, I, P, P, I, I, I, I, D, P, P]),
     "unetk_patch_gather": (I, [P, I, P, P, I, I, P, P, I, I, I, P, P, P, P]),
+    "unetk_metrics_num_partials": (I, [L]),
+    "unetk_metrics_update": (I, [P, P, L, P, P, P]),
     "unetk_nchw_to_nhwc": (I, [P, P, I, I, I, I, I, I, P]),
     "unetk_nhwc_to_nchw": (I, [P, I, P, I, I, I, I, I, P]),
     "unetk_bn_finalize": (I, [P, I, I, L, P, P, F, F, P, P, P, P, P, P, P]),
