@@ -41,6 +41,8 @@ CONV_SHAPES = [  # B, H, W, Ci, Co, ks
     (1, 16, 16, 48, 96, 3),
     (1, 37, 18, 144, 48, 3),
     (2, 8, 8, 96, 192, 3),
+    (2, 64, 48, 192, 96, 3),      # long K
+    (1, 40, 33, 288, 192, 3),     # ... ragged in both directions, several channel blocks
     (1, 5, 3, 24, 8, 3),
     (3, 9, 11, 64, 64, 1),
     (1, 40, 40, 96, 384, 1),
