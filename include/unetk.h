@@ -62,6 +62,15 @@ int unetk_conv_fwd_split(const void* in, int ldin, const void* wpacked, void* ou
                          int ldout2, int split, int B, int H, int W, int Ci, int Co, int ks, int bn,
                          int dtype, float* stats, const float* ep_scale, const float* ep_shift, int act,
                          const void* resid, int ldres, const float* resid_keep, unetk_stream_t stream);
+/* Same again, with inference-time fusions for 3x3 convs: pooled (nullable) receives the 2x2
+ * max-pool of the stored output (training.py:464-473, dense [B][H/2][W/2][Co]); head_out (nullable,
+ * NCHW fp32 [B][head_co][H][W]) receives the network's final 1x1 conv with bias applied to the
+ * stored output (training.py:482,520; needs Co <= bn).  out may be NULL when only head_out is wanted. */
+int unetk_conv_fwd_fused(const void* in, int ldin, const void* wpacked, void* out, int ldout, void* out2,
+                         int ldout2, int split, void* pooled, const float* head_w, const float* head_b,
+                         float* head_out, int head_co, int B, int H, int W, int Ci, int Co, int ks, int bn,
+                         int dtype, float* stats, const float* ep_scale, const float* ep_shift, int act,
+                         const void* resid, int ldres, const float* resid_keep, unetk_stream_t stream);
 /* dw[Co][Ci][k][k] (+)= sum_pixels dy (x) shifted in   (autograd of the convolutions above) */
 int64_t unetk_conv_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Co, int ks, int dtype);
 int unetk_conv_wgrad(const void* in, int ldin, const void* dy, int lddy, float* dw, int B, int H, int W,

@@ -228,3 +228,25 @@ def test_bad_arguments_raise():
         ops.conv_fwd(x, pw, Ci=6, Co=8)
     with pytest.raises(RuntimeError):
         ops.nchw_to_nhwc(torch.zeros(1, 1, 2, 2), torch.float32)   # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 20, 33, 16, 48), (1, 32, 32, 96, 96), (2, 9, 7, 8, 16)])
+def test_conv_fused_pool_and_head(dt, shape):
+    """Inference-time epilogue fusions: bit-identical max-pool, and the final 1x1 conv."""
+    from unet_amd import ops
+    B, H, W, Ci, Co = shape
+    x = nhwc(rnd((B, Ci, H, W), 21, dt), dt)
+    w = rnd((Co, Ci, 3, 3), 22, dt, (2.0 / (Ci * 9)) ** 0.5)
+    sc, sh = (torch.rand(Co) + 0.5).cuda(), (torch.randn(Co) * 0.3).cuda()
+    pw = ops.PackedConv(w.cuda(), dt)
+    y, _ = ops.conv_fwd(x, pw, scale=sc, shift=sh, act=1)
+    wide = torch.zeros((B, H, W, Co + 8), dtype=dt, device="cuda")
+    y2, pooled, none = ops.conv_fwd(x, pw, scale=sc, shift=sh, act=1, out=wide[..., 8:], pool=True)
+    assert none is None and torch.equal(y2, y) and torch.equal(pooled, ops.maxpool2x2(y))
+    if Co <= pw.bn:
+        hw, hb = torch.randn(2, Co, 1, 1).cuda() * 0.2, torch.randn(2).cuda()
+        o, p, head = ops.conv_fwd(x, pw, scale=sc, shift=sh, act=1, head=(hw, hb), write_out=False)
+        assert o is None and p is None
+        want = ops.head1x1_fwd(y, hw, hb)
+        assert rel(head.cpu(), want.cpu()) < 1e-5

@@ -43,6 +43,11 @@ struct ConvArgs {
   const float* ep_scale;   // [Co] or null (=1)
   const float* ep_shift;   // [Co] or null (=0)
   void* out2;              // output channels >= split go here (ld = ldout2), renumbered from 0; or null
+  void* pooled;            // 2x2 max-pool of the (post-activation) output, dense [B][H/2][W/2][Co]; or null
+  const float* head_w;     // fused trailing 1x1 conv: weights [head_co][Co] ...
+  const float* head_b;     // ... bias [head_co] or null ...
+  float* head_out;         // ... and its NCHW fp32 output [B][head_co][H][W]; or null
+  int head_co;
   const void* resid;       // residual (same layout as out, ld = ldres) or null
   const float* resid_keep; // per-sample scale applied to the conv result before the add, or null
   int ldin, ldout, ldres, ldout2, split;
@@ -76,7 +81,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
-template <typename T, int NT, int KS, bool HDB>
+template <typename T, int NT, int KS, bool HDB, bool FUSE>
 __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
   using M = MMA<T>;
   constexpr int KC = M::KC;
@@ -362,6 +367,65 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     esh[j] = (a.ep_shift != nullptr && c < a.Co) ? a.ep_shift[c] : 0.f;
   }
 
+  if constexpr (KS == 3 && FUSE) {
+    // Inference-time fusions on the values as they are stored (activation applied, rounded to T):
+    // a lane holds pixels (row 4*wave+i, column 4*pg+r), i.e. whole 2x2 quads, for its channels.
+    auto val = [&](int i, int j, int r) -> float {
+      float v = acc[i][j][r] * esc[j] + esh[j];
+      if (a.act == 1) v = fmaxf(v, 0.f);       // (the host admits only none / ReLU here)
+      return to_f32(from_f32<T>(v));
+    };
+    if (a.pooled != nullptr) {
+      T* pl = reinterpret_cast<T*>(a.pooled);
+      const int PH = a.H >> 1, PW = a.W >> 1;
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) {
+          const int py = (y0 + 4 * wave + 2 * i2) >> 1, px = (x0 + 4 * pg + 2 * r2) >> 1;
+          if (py < PH && px < PW) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+              const float m = fmaxf(fmaxf(val(2 * i2, j, 2 * r2), val(2 * i2, j, 2 * r2 + 1)),
+                                    fmaxf(val(2 * i2 + 1, j, 2 * r2), val(2 * i2 + 1, j, 2 * r2 + 1)));
+              const int c = n0 + j * 16 + cl;
+              if (c < a.Co) pl[(((long)b * PH + py) * PW + px) * a.Co + c] = from_f32<T>(m);
+            }
+          }
+        }
+    }
+    if (a.head_out != nullptr) {
+      // final 1x1 conv (few outputs): per-lane partial dot products over its channels, then a
+      // butterfly over the 16 lanes that share a pixel group
+      for (int o = 0; o < a.head_co; ++o) {
+        float hw[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int c = n0 + j * 16 + cl;
+          hw[j] = c < a.Co ? a.head_w[(long)o * a.Co + c] : 0.f;
+        }
+        const float hb = a.head_b ? a.head_b[o] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float sdot = 0.f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) sdot += val(i, j, r) * hw[j];
+            sdot += __shfl_xor(sdot, 1, 64);
+            sdot += __shfl_xor(sdot, 2, 64);
+            sdot += __shfl_xor(sdot, 4, 64);
+            sdot += __shfl_xor(sdot, 8, 64);
+            if (cl == 0 && pixel_valid(i, r)) {
+              const int gy = y0 + 4 * wave + i, gx = x0 + 4 * pg + r;
+              a.head_out[(((long)b * a.head_co + o) * a.H + gy) * a.W + gx] = sdot + hb;
+            }
+          }
+      }
+    }
+  }
+  if (a.out == nullptr) return;      // (uniform) only the fused outputs were wanted
+
   T* stage = reinterpret_cast<T*>(lds) + wave * 16 * BN;
   constexpr int PPP = BN / EPP;            // 16-byte parts per staged pixel
 #pragma unroll
@@ -404,17 +468,17 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
   }
 }
 
-template <typename T, int NT, int KS>
+template <typename T, int NT, int KS, bool FUSE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_igemm_kernel(ConvArgs a) {
-  conv_igemm_body<T, NT, KS, true>(a);
+  conv_igemm_body<T, NT, KS, true, FUSE>(a);
 }
 
 // Narrow layers move more bytes per flop than the MFMA-bound wide ones: they trade the second halo
 // buffer and registers for four workgroups per CU, so more loads are in flight.
-template <typename T, int NT, int KS>
+template <typename T, int NT, int KS, bool FUSE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_igemm_occ4_kernel(
     ConvArgs a) {
-  conv_igemm_body<T, NT, KS, false>(a);
+  conv_igemm_body<T, NT, KS, false, FUSE>(a);
 }
 
 // ---- weight packing: [Co][Ci][KS][KS] f32 -> [nblk][nchunk][tap][BN][KC] T
@@ -452,6 +516,21 @@ int launch_conv(ConvArgs a, int bn, hipStream_t stream) {
   a.tiles_per_xcd = cdiv(a.ntiles, 8);
   a.nby = cdiv(a.Co, bn);
   dim3 grid((unsigned)(8 * a.tiles_per_xcd * a.nby));
+  if constexpr (KS == 3) {
+    if (a.pooled != nullptr || a.head_out != nullptr) {      // inference-time fused epilogue
+      switch (bn) {
+        case 32: hipLaunchKernelGGL((conv_igemm_occ4_kernel<T, 2, KS, true>), grid, dim3(256), 0, stream, a); break;
+        case 48: hipLaunchKernelGGL((conv_igemm_occ4_kernel<T, 3, KS, true>), grid, dim3(256), 0, stream, a); break;
+        case 64: hipLaunchKernelGGL((conv_igemm_kernel<T, 4, KS, true>), grid, dim3(256), 0, stream, a); break;
+        case 96: hipLaunchKernelGGL((conv_igemm_kernel<T, 6, KS, true>), grid, dim3(256), 0, stream, a); break;
+        default:
+          unetk_set_error("conv: unsupported channel block %d (32, 48, 64 or 96)", bn);
+          return UNETK_EINVAL;
+      }
+      UNETK_CHECK_LAUNCH();
+      return UNETK_OK;
+    }
+  }
   if (KS == 3 && bn <= 48) {
     if (bn == 32) hipLaunchKernelGGL((conv_igemm_occ4_kernel<T, 2, KS>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((conv_igemm_occ4_kernel<T, 3, KS>), grid, dim3(256), 0, stream, a);
@@ -519,11 +598,19 @@ int unetk_conv_num_tiles(int B, int H, int W, int ks) {
   return cdiv((long)B * H * W, 256);
 }
 
-int unetk_conv_fwd_split(const void* in, int ldin, const void* wpacked, void* out, int ldout, void* out2,
-                         int ldout2, int split, int B, int H, int W, int Ci, int Co, int ks, int bn, int dtype,
-                         float* stats, const float* ep_scale, const float* ep_shift, int act,
+int unetk_conv_fwd_fused(const void* in, int ldin, const void* wpacked, void* out, int ldout, void* out2,
+                         int ldout2, int split, void* pooled, const float* head_w, const float* head_b,
+                         float* head_out, int head_co, int B, int H, int W, int Ci, int Co, int ks, int bn,
+                         int dtype, float* stats, const float* ep_scale, const float* ep_shift, int act,
                          const void* resid, int ldres, const float* resid_keep, hipStream_t stream) {
-  UNETK_CHECK_ARG(in && wpacked && out, "conv_fwd: null pointer");
+  UNETK_CHECK_ARG(in && wpacked && (out || head_out), "conv_fwd: null pointer");
+  UNETK_CHECK_ARG((pooled == nullptr && head_out == nullptr) || (ks == 3 && resid == nullptr && out2 == nullptr),
+                  "conv_fwd: pooled / head outputs need a 3x3 conv without residual or split");
+  UNETK_CHECK_ARG(head_out == nullptr || (head_w && head_co > 0 && Co <= bn),
+                  "conv_fwd: the fused 1x1 head needs all %d channels in one block of %d", Co, bn);
+  UNETK_CHECK_ARG((pooled == nullptr && head_out == nullptr) || act == 0 || act == 1,
+                  "conv_fwd: pooled / head outputs go with no activation or ReLU");
+  if (out == nullptr) ldout = Co;
   UNETK_CHECK_ARG(ks == 1 || ks == 3, "conv_fwd: kernel size %d (1 or 3)", ks);
   UNETK_CHECK_ARG(dtype == UNETK_F32 || dtype == UNETK_BF16, "conv_fwd: bad dtype %d", dtype);
   UNETK_CHECK_ARG(B > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0, "conv_fwd: bad shape");
@@ -547,6 +634,7 @@ int unetk_conv_fwd_split(const void* in, int ldin, const void* wpacked, void* ou
   ConvArgs a;
   a.in = in; a.w = wpacked; a.out = out; a.stats = stats;
   a.out2 = out2; a.ldout2 = ldout2; a.split = out2 ? split : 0;
+  a.pooled = pooled; a.head_w = head_w; a.head_b = head_b; a.head_out = head_out; a.head_co = head_co;
   a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.resid = resid; a.resid_keep = resid_keep;
   a.ldin = ldin; a.ldout = ldout; a.ldres = ldres;
   a.B = B; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
@@ -558,6 +646,15 @@ int unetk_conv_fwd_split(const void* in, int ldin, const void* wpacked, void* ou
   return ks == 3 ? launch_conv<float, 3>(a, bn, stream) : launch_conv<float, 1>(a, bn, stream);
 }
 
+
+int unetk_conv_fwd_split(const void* in, int ldin, const void* wpacked, void* out, int ldout, void* out2,
+                         int ldout2, int split, int B, int H, int W, int Ci, int Co, int ks, int bn, int dtype,
+                         float* stats, const float* ep_scale, const float* ep_shift, int act,
+                         const void* resid, int ldres, const float* resid_keep, hipStream_t stream) {
+  return unetk_conv_fwd_fused(in, ldin, wpacked, out, ldout, out2, ldout2, split, nullptr, nullptr, nullptr, nullptr,
+                              0, B, H, W, Ci, Co, ks, bn, dtype, stats, ep_scale, ep_shift, act, resid, ldres,
+                              resid_keep, stream);
+}
 
 int unetk_conv_fwd(const void* in, int ldin, const void* wpacked, void* out, int ldout, int B, int H,
                    int W, int Ci, int Co, int ks, int bn, int dtype, float* stats,

@@ -72,11 +72,15 @@ class PackedConv:
 
 def conv_fwd(x: torch.Tensor, pw: PackedConv, Ci: Optional[int] = None, Co: Optional[int] = None,
              out: Optional[torch.Tensor] = None, want_stats: bool = False, scale=None, shift=None,
-             act: int = 0, resid=None, resid_keep=None, split: int = 0):
+             act: int = 0, resid=None, resid_keep=None, split: int = 0, pool: bool = False, head=None,
+             write_out: bool = True):
     """x: (B,H,W,ld) NHWC.  Channel counts default to the packed weight's, rounded up to the
     vector width for the output (padding channels come out as exact zeros).  With ``split`` (a
     multiple of the packed channel block) the result is two tensors, channels [0,split) and
-    [split,Co), and the return value is ((out_a, out_b), stats)."""
+    [split,Co), and the return value is ((out_a, out_b), stats).  Inference-time fusions (3x3 only):
+    ``pool`` also returns the 2x2 max-pool of the output, ``head=(w, bias)`` the final 1x1 conv
+    (NCHW fp32) applied to it; with either the return value is (out, pooled, head_out) and
+    ``write_out=False`` skips the output itself."""
     B, H, W, _ = x.shape
     ldin = x.stride(2)
     dt = x.dtype
@@ -91,6 +95,21 @@ def conv_fwd(x: torch.Tensor, pw: PackedConv, Ci: Optional[int] = None, Co: Opti
              B, H, W, Ci, Co, pw.ks, pw.bn, dtype_code(dt), None, ptr(scale), ptr(shift), act, None, 0, None,
              stream())
         return (out, out2), None
+    if pool or head is not None:
+        if out is None and write_out:
+            out = torch.empty((B, H, W, Co), dtype=dt, device=x.device)
+        pooled = torch.empty((B, H // 2, W // 2, Co), dtype=dt, device=x.device) if pool else None
+        hw = hb = hout = None
+        hco = 0
+        if head is not None:
+            hw, hb = head
+            hco = hw.shape[0]
+            hw = hw.detach().reshape(hco, -1).float().contiguous()
+            hout = torch.empty((B, hco, H, W), dtype=torch.float32, device=x.device)
+        call("unetk_conv_fwd_fused", ptr(x), ldin, ptr(pw.data), ptr(out), out.stride(2) if out is not None else 0,
+             None, 0, 0, ptr(pooled), ptr(hw), ptr(hb), ptr(hout), hco, B, H, W, Ci, Co, pw.ks, pw.bn,
+             dtype_code(dt), None, ptr(scale), ptr(shift), act, None, 0, None, stream())
+        return out, pooled, hout
     if out is None:
         out = torch.empty((B, H, W, Co), dtype=dt, device=x.device)
     ldout = out.stride(2)          # `out` may be a channel slice of a wider (concat) buffer

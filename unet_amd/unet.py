@@ -143,11 +143,16 @@ class EvalEngine:
         self.head_w = model.conv.weight.detach()
         self.head_b = model.conv.bias.detach() if model.conv.bias is not None else None
 
-    def _block(self, name, t, out=None):
-        for ci in (0, 3):
-            sc, sh = self.fold[(name, ci)]
-            t, _ = ops.conv_fwd(t, self.pk[(name, ci)], scale=sc, shift=sh, act=1, out=out if ci == 3 else None)
-        return t
+    def _block(self, name, t, out=None, pool=False, head=None):
+        """Two conv+BN+ReLU units; the second can also hand back the max-pooled output, or only
+        the network's final 1x1 conv of it (both computed in its epilogue)."""
+        sc, sh = self.fold[(name, 0)]
+        t, _ = ops.conv_fwd(t, self.pk[(name, 0)], scale=sc, shift=sh, act=1)
+        sc, sh = self.fold[(name, 3)]
+        if pool or head is not None:
+            return ops.conv_fwd(t, self.pk[(name, 3)], scale=sc, shift=sh, act=1, out=out, pool=pool, head=head,
+                                write_out=head is None)
+        return ops.conv_fwd(t, self.pk[(name, 3)], scale=sc, shift=sh, act=1, out=out)[0]
 
     def _encoder(self, name, dec, t):
         """An encoder block writes straight into the skip half of its decoder's concat buffer."""
@@ -156,8 +161,8 @@ class EvalEngine:
         C1 = dseq[0].in_channels - C2
         B, H, W, _ = t.shape
         cat = torch.empty((B, H, W, C1 + C2), dtype=t.dtype, device=t.device)
-        e = self._block(name, t, out=cat[..., C1:])
-        return cat, ops.maxpool2x2(e)
+        _, pooled, _ = self._block(name, t, out=cat[..., C1:], pool=True)
+        return cat, pooled
 
     def __call__(self, h):
         cat1, p = self._encoder("encoder1", "decoder1", h)
@@ -165,8 +170,12 @@ class EvalEngine:
         cat3, p = self._encoder("encoder3", "decoder3", p)
         cat4, p = self._encoder("encoder4", "decoder4", p)
         d = self._block("bottleneck", p)
-        for name, cat in (("decoder4", cat4), ("decoder3", cat3), ("decoder2", cat2), ("decoder1", cat1)):
+        for name, cat in (("decoder4", cat4), ("decoder3", cat3), ("decoder2", cat2)):
             d = self._block(name, ops.upsample_into(d, cat))
+        last = self.pk[("decoder1", 3)]
+        if last.Co <= last.bn:           # the head needs every channel in one workgroup
+            return self._block("decoder1", ops.upsample_into(d, cat1), head=(self.head_w, self.head_b))[2]
+        d = self._block("decoder1", ops.upsample_into(d, cat1))
         return ops.head1x1_fwd(d, self.head_w, self.head_b)
 
 
