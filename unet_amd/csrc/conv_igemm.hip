@@ -100,8 +100,12 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
   constexpr int WINSTR = (WROWS * 4) / 64;              // per weight slab (BN multiple of 16: exact)
   static_assert((WROWS * 4) % 64 == 0, "weight slab must be whole wave instructions");
   constexpr int HBUF = HINSTR * 1024, WBUF = WINSTR * 1024;
-  constexpr int NHB = HDB ? 2 : 1;                      // halo buffers
-  constexpr int MAIN_BYTES = NHB * HBUF + 2 * WBUF;
+  // 1x1 (plain GEMM) phases are a third as long as 3x3 ones: they get rings of three stages, two
+  // phases of operands in flight behind the one in use, behind counted waits
+  constexpr bool RING3 = HDB && KS == 1;
+  constexpr int NHB = RING3 ? 3 : (HDB ? 2 : 1);        // halo buffers
+  constexpr int NWB = RING3 ? 3 : 2;                    // weight buffers
+  constexpr int MAIN_BYTES = NHB * HBUF + NWB * WBUF;
   constexpr int STAGE_BYTES = 4 * 16 * BN * (int)sizeof(T);
   constexpr int RED_BYTES = 4 * 2 * BN * (int)sizeof(float);
   constexpr int LDS_BYTES = MAIN_BYTES > STAGE_BYTES + RED_BYTES ? MAIN_BYTES : STAGE_BYTES + RED_BYTES;
@@ -173,7 +177,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
   const T* halo_base = (KS == 3) ? in + (((long)b * a.H + (y0 - 1)) * a.W + (x0 - 1)) * a.ldin : in + p0 * a.ldin;
   const unsigned rows_left = (KS == 3) ? 0u : (unsigned)((npix - p0 < 256) ? (npix - p0) : 256);
   auto issue_halo = [&](int ch) {
-    char* dst = lds + (HDB ? (ch & 1) : 0) * HBUF;
+    char* dst = lds + (RING3 ? ch % 3 : (HDB ? (ch & 1) : 0)) * HBUF;
     const int c0 = ch * KC;
     const T* base = halo_base + c0;
     const int climit = a.Ci - c0;                         // channel slots below this exist
@@ -217,7 +221,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
   const int w_rel = (lane >> 2) * KC + ((lane & 3) ^ swz(lane >> 2)) * EPP;
   auto issue_w = [&](int phase) {
     const int ch = phase / KS, ky = phase - ch * KS;
-    char* dst = lds + NHB * HBUF + (phase & 1) * WBUF;
+    char* dst = lds + NHB * HBUF + (RING3 ? phase % 3 : (phase & 1)) * WBUF;
     const T* wsrc = wp + ((((long)nb * a.nchunks + ch) * TAPS + ky * KS) * BN) * KC + w_rel;
     for (int i = wave; i < WINSTR; i += 4) glds16(wsrc + i * (1024 / (int)sizeof(T)), dst + i * 1024);
   };
@@ -225,8 +229,12 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
   const int nphase = a.nchunks * KS;
   issue_halo(0);
   issue_w(0);
-  // halo pieces this wave issues per chunk, and whether a halo issued one phase ago is in flight
-  const int my_halo = (HINSTR - wave + 3) / 4;
+  if (RING3 && nphase > 1) {
+    issue_halo(1);
+    issue_w(1);
+  }
+  // DMA pieces this wave issues per halo / weight slab, and whether a halo issued one phase ago is in flight
+  const int my_halo = (HINSTR - wave + 3) / 4, my_w = (WINSTR - wave + 3) / 4;
   bool halo_flying = false;
 
   // bf16 fragment addresses without per-read arithmetic.  A fragment read is row (R + l15), 16-byte
@@ -243,10 +251,19 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
 
 #pragma unroll 1
   for (int ch = 0; ch < a.nchunks; ++ch) {
-    const char* lds_halo = lds + (HDB ? (ch & 1) : 0) * HBUF;
+    const char* lds_halo = lds + (RING3 ? ch % 3 : (HDB ? (ch & 1) : 0)) * HBUF;
 #pragma unroll
     for (int ky = 0; ky < KS; ++ky) {
       const int phase = ch * KS + ky;
+      if constexpr (RING3) {
+        // phase == chunk.  Needed now: halo and weights of this phase (issued two phases ago);
+        // the next phase's pieces are younger and stay in flight.
+        wait_vm_barrier(phase + 1 < nphase ? my_halo + my_w : 0);
+        if (phase + 2 < nphase) {
+          issue_halo(phase + 2);
+          issue_w(phase + 2);
+        }
+      } else {
       // The weights of this phase (and at ky == 0 its halo) have landed for every wave, and everyone
       // is done with phase-1's buffers.  With two halo buffers the next chunk's halo is issued in the
       // chunk's first phase, after that phase's weight prefetch: at the next barrier it is the newest
@@ -264,7 +281,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
         halo_flying = ch + 1 < a.nchunks;
         if (halo_flying) issue_halo(ch + 1);
       }
-      const char* lds_w = lds + NHB * HBUF + (phase & 1) * WBUF;
+      }
+      const char* lds_w = lds + NHB * HBUF + (RING3 ? phase % 3 : (phase & 1)) * WBUF;
 #pragma unroll
       for (int kx = 0; kx < KS; ++kx) {
 #pragma unroll

@@ -398,6 +398,17 @@ WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int dtype) {
   return p;
 }
 
+// A 1x1 weight gradient is a plain sum over pixels: any 2-D shape of the pixel axis will do, so the
+// pixels are refolded into 32-pixel rows and every 256-pixel tile is full whatever the image size.
+inline void refold_1x1(int& B, int& H, int& W, int ks) {
+  const long npix = (long)B * H * W;
+  if (ks == 1 && npix % 32 == 0 && npix / 32 < (1L << 30)) {
+    B = 1;
+    H = (int)(npix / 32);
+    W = 32;
+  }
+}
+
 template <typename T, int KS>
 int launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t stream) {
   dim3 grid((unsigned)(a.gx * a.gy * p.nsplit));
@@ -421,6 +432,7 @@ int launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t stream) {
 extern "C" {
 
 int64_t unetk_conv_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Co, int ks, int dtype) {
+  refold_1x1(B, H, W, ks);
   const WgradPlan p = plan_wgrad(B, H, W, Ci, Co, dtype);
   return (int64_t)p.nsplit * p.Co_pad * ks * ks * p.Ci_pad * 4;
 }
@@ -435,6 +447,7 @@ int unetk_conv_wgrad(const void* in, int ldin, const void* dy, int lddy, float* 
   UNETK_CHECK_ARG(Ci % epp == 0 && Co % epp == 0 && ldin % epp == 0 && lddy % epp == 0,
                   "conv_wgrad: channels and strides must be multiples of %d", epp);
   UNETK_CHECK_ARG(((uintptr_t)in % 16) == 0 && ((uintptr_t)dy % 16) == 0, "conv_wgrad: misaligned pointer");
+  refold_1x1(B, H, W, ks);
   const WgradPlan p = plan_wgrad(B, H, W, Ci, Co, dtype);
   const int64_t need = unetk_conv_wgrad_workspace_bytes(B, H, W, Ci, Co, ks, dtype);
   UNETK_CHECK_ARG(workspace_bytes >= need, "conv_wgrad: workspace %lld < %lld bytes",
