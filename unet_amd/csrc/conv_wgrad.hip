@@ -85,8 +85,12 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
   constexpr int TR = TPIX / TW;
   constexpr int BM = MT * 16;
   constexpr int NWK = 8 / NWN;                  // k-step residues (waves along K)
-  constexpr int KCI = NWN * 16;                 // input channels per workgroup
+  // 1x1 (plain GEMM) with NWN == 1: there are no taps to amortise the dy fragments over, so every
+  // wave takes four 16-channel slices of a 64-channel chunk and the eight waves only split K
+  constexpr int NSL = (BF && KS == 1 && NWN == 1) ? 4 : 1;
+  constexpr int KCI = NWN * NSL * 16;           // input channels per workgroup
   constexpr int TAPS = KS * KS;
+  constexpr int NACC = TAPS * NSL;              // accumulator tiles per 16 output channels
   constexpr int HW_ = (KS == 3) ? TW + 2 : TW;  // halo width
   constexpr int HH_ = (KS == 3) ? TR + 2 : TR;
   constexpr int HPIX = HH_ * HW_;
@@ -129,11 +133,11 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
   const T* dy = reinterpret_cast<const T*>(a.dy);
   const T* zero = reinterpret_cast<const T*>(wgrad_zero_page);
 
-  f32x4 acc[MT][TAPS];
+  f32x4 acc[MT][NACC];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NACC; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int g = lane >> 4, li = lane & 15, q = li >> 2, p4 = li & 3;
 
@@ -191,38 +195,41 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
           af[m] = tr_read8(lds_dy + dy_row<RBD>(pk0) * RBD + dy_slot<RBD>(pk0, 2 * m + (p4 >> 1)) * 16 + (p4 & 1) * 8,
                            lds_dy + dy_row<RBD>(pk1) * RBD + dy_slot<RBD>(pk1, 2 * m + (p4 >> 1)) * 16 + (p4 & 1) * 8);
         const int r0 = pk0 / TW, c0_ = pk0 - r0 * TW;
-        const int slot = wn * 2 + (p4 >> 1), sub = (p4 & 1) * 8;
+        const int sub = (p4 & 1) * 8;
         // A lane's eight k-slots are eight consecutive pixels of one image row, so the three
         // horizontal taps are the 8-pixel windows at offsets 0, 1, 2 of a 12-pixel run: three
         // transposing reads per kernel row, the windows cut out of them in registers.
 #pragma unroll
-        for (int ky = 0; ky < KS; ++ky) {
-          const int hr = (r0 + ky) * HW_ + c0_;
-          u32x2 t[KS == 3 ? 3 : 2];
+        for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
-          for (int i = 0; i < (KS == 3 ? 3 : 2); ++i) {
-            const int row = hr + 4 * i;
-            t[i] = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(
-                                                 short4v, lds_h + row * RBH + hswz<RBH>(row, slot) * 16 + sub)));
-          }
-          u32x4 win[KS];
-          win[0] = u32x4{t[0][0], t[0][1], t[1][0], t[1][1]};
-          if constexpr (KS == 3) {
-            win[1] = u32x4{__builtin_amdgcn_alignbit(t[0][1], t[0][0], 16),
-                           __builtin_amdgcn_alignbit(t[1][0], t[0][1], 16),
-                           __builtin_amdgcn_alignbit(t[1][1], t[1][0], 16),
-                           __builtin_amdgcn_alignbit(t[2][0], t[1][1], 16)};
-            win[2] = u32x4{t[0][1], t[1][0], t[1][1], t[2][0]};
-          }
+          for (int sl = 0; sl < NSL; ++sl) {
+            const int slot = (wn * NSL + sl) * 2 + (p4 >> 1);
+            const int hr = (r0 + ky) * HW_ + c0_;
+            u32x2 t[KS == 3 ? 3 : 2];
 #pragma unroll
-          for (int kx = 0; kx < KS; ++kx) {
-            const bf16x8 bfr = __builtin_bit_cast(bf16x8, win[kx]);
+            for (int i = 0; i < (KS == 3 ? 3 : 2); ++i) {
+              const int row = hr + 4 * i;
+              t[i] = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(
+                                                   short4v, lds_h + row * RBH + hswz<RBH>(row, slot) * 16 + sub)));
+            }
+            u32x4 win[KS];
+            win[0] = u32x4{t[0][0], t[0][1], t[1][0], t[1][1]};
+            if constexpr (KS == 3) {
+              win[1] = u32x4{__builtin_amdgcn_alignbit(t[0][1], t[0][0], 16),
+                             __builtin_amdgcn_alignbit(t[1][0], t[0][1], 16),
+                             __builtin_amdgcn_alignbit(t[1][1], t[1][0], 16),
+                             __builtin_amdgcn_alignbit(t[2][0], t[1][1], 16)};
+              win[2] = u32x4{t[0][1], t[1][0], t[1][1], t[2][0]};
+            }
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-              acc[m][ky * KS + kx] =
-                  __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr, acc[m][ky * KS + kx], 0, 0, 0);
+            for (int kx = 0; kx < KS; ++kx) {
+              const bf16x8 bfr = __builtin_bit_cast(bf16x8, win[kx]);
+#pragma unroll
+              for (int m = 0; m < MT; ++m)
+                acc[m][(ky * KS + kx) * NSL + sl] =
+                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr, acc[m][(ky * KS + kx) * NSL + sl], 0, 0, 0);
+            }
           }
-        }
       }
     } else {
       // k-step = 4 consecutive tile pixels; A[m=lane&15][k=lane>>4], B[k=lane>>4][n=lane&15]
@@ -295,7 +302,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
 
   // Sum the k-residues of the workgroup through LDS (fixed order: residue w + half into w, halving),
   // one 16-channel row block at a time so the exchange area is 4 waves x 9 KiB at most.
-  static_assert(4 * TAPS * 4 * 64 * 4 <= STAGE, "exchange area");
+  static_assert(4 * NACC * 4 * 64 * 4 <= STAGE, "exchange area");
+  static_assert(BF || NSL == 1, "channel slices per wave: bf16 only");
   float* xch = reinterpret_cast<float*>(buf0);
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
@@ -303,17 +311,17 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
     for (int half = NWK / 2; half >= 1; half >>= 1) {
       __syncthreads();   // (first trip: every wave is done with the last tile)
       if (wk >= half && wk < 2 * half) {
-        float* dst = xch + ((wk - half) * NWN + wn) * (TAPS * 4 * 64) + lane;
+        float* dst = xch + ((wk - half) * NWN + wn) * (NACC * 4 * 64) + lane;
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t)
+        for (int t = 0; t < NACC; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) dst[(t * 4 + r) * 64] = acc[m][t][r];
       }
       __syncthreads();
       if (wk < half) {
-        const float* src = xch + (wk * NWN + wn) * (TAPS * 4 * 64) + lane;
+        const float* src = xch + (wk * NWN + wn) * (NACC * 4 * 64) + lane;
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t)
+        for (int t = 0; t < NACC; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[m][t][r] += src[(t * 4 + r) * 64];
       }
@@ -328,11 +336,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int co = co0 + m * 16 + 4 * g + r;
-        const int ci = ci0 + wn * 16 + li;
-        slab[((long)co * TAPS + t) * a.Ci_pad + ci] = acc[m][t][r];
-      }
+      for (int sl = 0; sl < NSL; ++sl)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = co0 + m * 16 + 4 * g + r;
+          const int ci = ci0 + (wn * NSL + sl) * 16 + li;
+          slab[((long)co * TAPS + t) * a.Ci_pad + ci] = acc[m][t * NSL + sl][r];
+        }
 }
 
 // dw[co][ci][tap] (+)= sum_s slab[s][co][tap][ci].  One workgroup per (co, tap, 32-channel chunk):
@@ -369,7 +379,7 @@ struct WgradPlan {
   int mt, tw, nwn, nwk, tpix, tr, tiles_x, tiles_y, ntiles, nsplit, Co_pad, Ci_pad;
 };
 
-WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int dtype) {
+WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int dtype, int ks) {
   WgradPlan p;
   p.mt = (Co % 48 == 0) ? 3 : ((Co % 64 == 0 || Co > 48) ? 4 : (Co > 32 ? 3 : 2));
   p.tw = (W <= 16) ? 16 : 32;
@@ -379,6 +389,7 @@ WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int dtype) {
   const bool low_intensity = 9.0 * Co * Ci / (Co + Ci) < 350.0;
   p.nwn = (dtype == UNETK_BF16 && (Ci % 64 == 0 || (Ci > 256 && (Ci % 64) > 32) || (low_intensity && Ci > 32)))
               ? 4 : 2;
+  if (ks == 1 && dtype == UNETK_BF16 && Ci >= 64) p.nwn = 1;   // plain GEMM: 4 channel slices per wave
   p.nwk = 8 / p.nwn;
   p.tpix = dtype == UNETK_BF16 ? 256 : 128;
   p.tr = p.tpix / p.tw;
@@ -386,7 +397,7 @@ WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int dtype) {
   p.tiles_y = cdiv(H, p.tr);
   p.ntiles = B * p.tiles_x * p.tiles_y;
   p.Co_pad = cdiv(Co, p.mt * 16) * p.mt * 16;
-  const int kci = p.nwn * 16;
+  const int kci = p.nwn == 1 ? 64 : p.nwn * 16;
   p.Ci_pad = cdiv(Ci, kci) * kci;
   const int gxy = (p.Ci_pad / kci) * (p.Co_pad / (p.mt * 16));
   int s = 768 / gxy;                       // one workgroup per CU: aim at ~3 rounds of 256
@@ -421,6 +432,9 @@ int launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t stream) {
   WG_CASE(2, 16, 2) WG_CASE(2, 32, 2) WG_CASE(3, 16, 2) WG_CASE(3, 32, 2) WG_CASE(4, 16, 2) WG_CASE(4, 32, 2)
   if constexpr (sizeof(T) == 2) {   // 64-channel chunks only fit LDS with 2-byte elements
     WG_CASE(2, 16, 4) WG_CASE(2, 32, 4) WG_CASE(3, 16, 4) WG_CASE(3, 32, 4) WG_CASE(4, 16, 4) WG_CASE(4, 32, 4)
+    if constexpr (KS == 1) {
+      WG_CASE(2, 16, 1) WG_CASE(2, 32, 1) WG_CASE(3, 16, 1) WG_CASE(3, 32, 1) WG_CASE(4, 16, 1) WG_CASE(4, 32, 1)
+    }
   }
 #undef WG_CASE
   unetk_set_error("conv_wgrad: no kernel for mt=%d tw=%d nwn=%d", p.mt, p.tw, p.nwn);
@@ -433,7 +447,7 @@ extern "C" {
 
 int64_t unetk_conv_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Co, int ks, int dtype) {
   refold_1x1(B, H, W, ks);
-  const WgradPlan p = plan_wgrad(B, H, W, Ci, Co, dtype);
+  const WgradPlan p = plan_wgrad(B, H, W, Ci, Co, dtype, ks);
   return (int64_t)p.nsplit * p.Co_pad * ks * ks * p.Ci_pad * 4;
 }
 
@@ -448,7 +462,7 @@ int unetk_conv_wgrad(const void* in, int ldin, const void* dy, int lddy, float* 
                   "conv_wgrad: channels and strides must be multiples of %d", epp);
   UNETK_CHECK_ARG(((uintptr_t)in % 16) == 0 && ((uintptr_t)dy % 16) == 0, "conv_wgrad: misaligned pointer");
   refold_1x1(B, H, W, ks);
-  const WgradPlan p = plan_wgrad(B, H, W, Ci, Co, dtype);
+  const WgradPlan p = plan_wgrad(B, H, W, Ci, Co, dtype, ks);
   const int64_t need = unetk_conv_wgrad_workspace_bytes(B, H, W, Ci, Co, ks, dtype);
   UNETK_CHECK_ARG(workspace_bytes >= need, "conv_wgrad: workspace %lld < %lld bytes",
                   (long long)workspace_bytes, (long long)need);
@@ -456,7 +470,7 @@ int unetk_conv_wgrad(const void* in, int ldin, const void* dy, int lddy, float* 
   a.in = in; a.dy = dy; a.slab = (float*)workspace; a.ldin = ldin; a.lddy = lddy;
   a.B = B; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.Ci_pad = p.Ci_pad; a.Co_pad = p.Co_pad;
   a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.ntiles = p.ntiles; a.nsplit = p.nsplit;
-  a.gx = p.Ci_pad / (p.nwn * 16); a.gy = p.Co_pad / (p.mt * 16);
+  a.gx = p.Ci_pad / (p.nwn == 1 ? 64 : p.nwn * 16); a.gy = p.Co_pad / (p.mt * 16);
   int rc;
   if (dtype == UNETK_BF16)
     rc = ks == 3 ? launch_wgrad<bf16, 3>(a, p, stream) : launch_wgrad<bf16, 1>(a, p, stream);
