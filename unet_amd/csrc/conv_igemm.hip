@@ -21,6 +21,7 @@
 // kernel, weights packed transposed and flipped), Swin linear layers as 1x1.
 #include "common.h"
 #include "mma.h"
+#include <type_traits>
 
 namespace {
 
@@ -249,6 +250,120 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     a_lane[c] = (4 * wave * (KS == 3 ? HALO : 16) + l15) * ROWB + ((q ^ swz(c + l15)) * 16);
   const int w_lane = l15 * ROWB + ((q ^ swz(l15)) * 16);
 
+  // The MFMA-bound 3x3 bf16 variant keeps two register sets of fragments: while step (ky, kx)
+  // multiplies from one, the ds_reads of the next step fill the other, one read every few MFMAs,
+  // so no MFMA ever waits on an LDS round trip.  For the reads to run ahead across a phase
+  // boundary, the barrier that opens phase q (and the DMA issue that follows it) sits before the
+  // LAST step of phase q-1: by then every wave has its fragments of that last step in registers
+  // (lgkmcnt(0) before the barrier), so nobody reads the buffers the DMA refills any more.
+  constexpr bool PIPE = HDB && KS == 3 && sizeof(T) == 2;
+  if constexpr (PIPE) {
+    using frag = typename M::frag;
+    frag fa[2][4], fb[2][NT];
+    auto load_frags = [&](auto bufc, auto tc, auto parc) {
+      // fragments of step t of a chunk with parity par (halo buffer par, weight buffer (par + ky) & 1)
+      constexpr int BUF = decltype(bufc)::value, t = decltype(tc)::value % TAPS;
+      constexpr int par = (decltype(parc)::value + decltype(tc)::value / TAPS) & 1;
+      constexpr int ky = t / KS, kx = t % KS;
+      const char* halo = lds + par * HBUF;
+      const char* wbuf = lds + NHB * HBUF + ((par + ky) & 1) * WBUF;
+      // (weights first: the next step's first MFMAs need all of them but only the first halo row)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        fb[BUF][j] = *reinterpret_cast<const frag*>(wbuf + w_lane + (kx * BN + j * 16) * ROWB);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = (2 * (i + ky) + kx) & 7;
+        fa[BUF][i] = *reinterpret_cast<const frag*>(halo + a_lane[c] + ((i + ky) * HALO + kx) * ROWB);
+      }
+    };
+    bool halo_fly = false;
+    auto open_phase = [&](int q, int vm_keep) {
+      // q: the phase whose operands must have landed; afterwards the DMA of phase q+1 goes out
+      switch (vm_keep) {
+#ifdef EXP_NOWAIT
+#define UNETK_WLB(N) case N: asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+#elif defined(EXP_NOBAR)
+#define UNETK_WLB(N) case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory"); break;
+#else
+#define UNETK_WLB(N) case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+#endif
+        UNETK_WLB(1) UNETK_WLB(2) UNETK_WLB(3) UNETK_WLB(4) UNETK_WLB(5) UNETK_WLB(6) UNETK_WLB(7) UNETK_WLB(8)
+#ifdef EXP_NOWAIT
+        default: asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+#elif defined(EXP_NOBAR)
+        default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+#else
+        default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+#endif
+#undef UNETK_WLB
+      }
+#if !defined(EXP_NODMA) && !defined(EXP_NOW)
+      if (q + 1 < nphase) issue_w(q + 1);
+#endif
+    };
+    auto chunk = [&](auto parc, int ch) {
+      constexpr int PAR = decltype(parc)::value;
+      auto step = [&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int ky = t / KS, kx = t % KS;
+        constexpr int cur = (t + PAR) & 1;
+        if constexpr (kx == KS - 1) {
+          const int q = ch * KS + ky + 1;
+          if (q < nphase) {
+            if constexpr (ky == KS - 1) {
+              // q opens chunk ch+1: its halo was drained at the previous barrier
+              open_phase(q, 0);
+              halo_fly = ch + 2 < a.nchunks;
+#if !defined(EXP_NODMA) && !defined(EXP_NOH)
+              if (halo_fly) issue_halo(ch + 2);
+#else
+              halo_fly = false;
+#endif
+            } else {
+              open_phase(q, (ky == 0 && halo_fly) ? my_halo : 0);
+            }
+          }
+        }
+        // (after a chunk's last step this reads the other halo buffer: the next chunk, or, at the
+        // very end, stale data nobody uses)
+        load_frags(std::integral_constant<int, cur ^ 1>{}, std::integral_constant<int, t + 1>{}, parc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = M::mma(fa[cur][i], fb[cur][j], acc[i][j]);
+        constexpr int NRD = 4 + NT, MPR = (4 * NT) / NRD;
+#pragma unroll
+        for (int k = 0; k < NRD; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);   // MPR MFMAs ...
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // ... then one ds_read
+        }
+        if constexpr (4 * NT - MPR * NRD > 0) __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT - MPR * NRD, 0);
+      };
+      step(std::integral_constant<int, 0>{});
+      step(std::integral_constant<int, 1>{});
+      step(std::integral_constant<int, 2>{});
+      step(std::integral_constant<int, 3>{});
+      step(std::integral_constant<int, 4>{});
+      step(std::integral_constant<int, 5>{});
+      step(std::integral_constant<int, 6>{});
+      step(std::integral_constant<int, 7>{});
+      step(std::integral_constant<int, 8>{});
+    };
+    // phase 0: everything issued so far has to land; then the first fragments (the one exposed read)
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (nphase > 1) issue_w(1);
+    halo_fly = a.nchunks > 1;
+    if (halo_fly) issue_halo(1);
+    load_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    int ch = 0;
+#pragma unroll 1
+    for (; ch + 1 < a.nchunks; ch += 2) {
+      chunk(std::integral_constant<int, 0>{}, ch);
+      chunk(std::integral_constant<int, 1>{}, ch + 1);
+    }
+    if (ch < a.nchunks) chunk(std::integral_constant<int, 0>{}, ch);
+  } else {
 #pragma unroll 1
   for (int ch = 0; ch < a.nchunks; ++ch) {
     const char* lds_halo = lds + (RING3 ? ch % 3 : (HDB ? (ch & 1) : 0)) * HBUF;
@@ -316,6 +431,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
         }
       }
     }
+  }
   }
 
   // ---- epilogue.  C layout: column (channel) = lane&15, row (pixel) = 4*(lane>>4)+r.
