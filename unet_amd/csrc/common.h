@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
+#include <utility>
 
 #include "../../include/unetk.h"
 
@@ -48,6 +50,16 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+}
+
+// f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N-1>{}): a loop whose
+// index is a constant expression in the body (template arguments, builtin immediates).
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
 // Error plumbing shared by the C-ABI entry points.

@@ -51,13 +51,17 @@ __device__ __forceinline__ bf16x8 tr_read8(const char* p0, const char* p1) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
-// Slot swizzle of the (unpadded, lane-linear) halo image.  A transposing read touches, per
-// 32-lane half, the rows {o..o+3, o+8..o+11} at one 32-byte column unit; XORing the unit index
-// with row bits 1 and 3 (128-byte rows) or bit 3 (64-byte rows) spreads those eight rows over
-// eight distinct 32-byte units of the 256-byte bank row: conflict-free.
-template <int ROW_BYTES> __device__ __forceinline__ int hswz(int row, int slot16) {
-  if (ROW_BYTES == 64) return slot16 ^ (((row >> 3) & 1) << 1);
-  if (ROW_BYTES == 128) return slot16 ^ ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1);
+// Slot swizzle of the (unpadded, lane-linear) halo image, keyed on the pixel's COLUMN in the halo.
+// A transposing read touches, per 32-lane half, the pixels {o..o+3, o+8..o+11} of one halo row at
+// one 32-byte column unit; XORing the unit index with column bits 1 and 3 (128-byte rows) or bit 3
+// (64-byte rows) spreads those eight pixels over eight distinct 32-byte units of the 256-byte bank
+// row (the halo width is even, so a pixel's row parity in the image is its column parity):
+// conflict-free.  Because the key ignores the halo row, the reads of another kernel row or k-step
+// are the same lane address plus a compile-time offset.  (The dy image uses it with the tile pixel
+// as key: k-steps are 32 pixels apart, which leaves bits 1 and 3 alone.)
+template <int ROW_BYTES> __device__ __forceinline__ int hswz(int col, int slot16) {
+  if (ROW_BYTES == 64) return slot16 ^ (((col >> 3) & 1) << 1);
+  if (ROW_BYTES == 128) return slot16 ^ ((((col >> 1) & 1) | (((col >> 3) & 1) << 1)) << 1);
   return slot16;
 }
 
@@ -141,6 +145,36 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
 
   const int g = lane >> 4, li = lane & 15, q = li >> 2, p4 = li & 3;
 
+  // DMA source tables: what depends on the lane and the piece but not on the tile, two registers
+  // a piece.  off = element offset from the tile's (halo's) first pixel and the workgroup's first
+  // channel; yx = the pixel's row and column in the tile (halo), or a row no image has when the
+  // piece's lanes lie past the tile or past the channel count.  (Kept this small on purpose: left
+  // to itself the compiler keeps a 64-bit address and more per piece, which spills next to the
+  // accumulators, and a spill reload beside the DMA waits for vmcnt(0).)
+  int d_off[DPW], d_yx[DPW], h_off[HPW], h_yx[HPW];
+#pragma unroll
+  for (int k = 0; k < DPW; ++k) {                 // dy tile: [pixel][BM channels]
+    int i = wave + 8 * k;
+    if (i >= DINSTR) i = DINSTR - 1;
+    const int part = i * 64 + lane;
+    const int row = part / PPD, rslot = part - row * PPD;          // position in the LDS image
+    const int pix = BF ? dy_pix<RBD>(row) : row;
+    const int slot = BF ? dy_slot<RBD>(pix, rslot) : rslot;
+    const int tr = pix / TW, tc = pix - tr * TW;
+    d_off[k] = (tr * a.W + tc) * a.lddy + slot * EPP;
+    d_yx[k] = (pix < TPIX && co0 + slot * EPP < a.Co) ? ((tr << 16) | tc) : (0x7fff << 16);
+  }
+#pragma unroll
+  for (int k = 0; k < HPW; ++k) {                 // input halo: [(TR+2)*(TW+2) pixels][KCI channels]
+    int i = wave + 8 * k;
+    if (i >= HINSTR) i = HINSTR - 1;
+    const int part = i * 64 + lane;
+    const int pix = part / PPH, slot = part - pix * PPH;
+    const int hy = pix / HW_, hx = pix - hy * HW_;
+    const int cs = hswz<RBH>(hx, slot) * EPP;
+    h_off[k] = (hy * a.W + hx) * a.ldin + cs;
+    h_yx[k] = (pix < HPIX && ci0 + cs < a.Ci) ? ((hy << 16) | hx) : (0x7fff << 16);
+  }
   auto issue_tile = [&](int tile, char* dbuf) {
     int t = tile;
     const int tx = t % a.tiles_x;
@@ -148,89 +182,119 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
     const int ty = t % a.tiles_y;
     const int b = t / a.tiles_y;
     const int y0 = ty * TR, x0 = tx * TW;
+    const int ph = (KS == 3) ? 1 : 0;             // halo origin = tile origin - ph
     char* hbuf = dbuf + DBUF;
+    // element offsets of the tile's / halo's first pixel (the host checks that they fit 31 bits);
+    // added to the lane's offset in 32 bits
+    const int d0 = ((b * a.H + y0) * a.W + x0) * a.lddy + co0;
+    const int h0 = ((b * a.H + y0 - ph) * a.W + x0 - ph) * a.ldin + ci0;
 #pragma unroll
-    for (int k = 0; k < DPW; ++k) {               // dy tile: [pixel][BM channels]
+    for (int k = 0; k < DPW; ++k) {
       int i = wave + 8 * k;
       if (i >= DINSTR) i = DINSTR - 1;
-      const int part = i * 64 + lane;
-      const int row = part / PPD, rslot = part - row * PPD;        // position in the LDS image
-      const int pix = BF ? dy_pix<RBD>(row) : row;
-      const int slot = BF ? dy_slot<RBD>(pix, rslot) : rslot;
-      const int tr = pix / TW, tc = pix - tr * TW;
-      const int gy = y0 + tr, gx = x0 + tc;
-      const int c = co0 + slot * EPP;
-      const T* src = zero;
-      if (pix < TPIX && gy < a.H && gx < a.W && c < a.Co)
-        src = dy + (((long)b * a.H + gy) * a.W + gx) * a.lddy + c;
-      glds16(src, dbuf + i * 1024);
+      const bool ok = y0 + (d_yx[k] >> 16) < a.H && x0 + (d_yx[k] & 0xffff) < a.W;
+      glds16(ok ? dy + (unsigned)(d0 + d_off[k]) : zero, dbuf + i * 1024);
     }
 #pragma unroll
-    for (int k = 0; k < HPW; ++k) {               // input halo: [(TR+2)*(TW+2) pixels][KCI channels]
+    for (int k = 0; k < HPW; ++k) {
       int i = wave + 8 * k;
       if (i >= HINSTR) i = HINSTR - 1;
-      const int part = i * 64 + lane;
-      const int pix = part / PPH, slot = part - pix * PPH;
-      const int hy = pix / HW_, hx = pix - hy * HW_;
-      const int gy = y0 + hy - (KS == 3 ? 1 : 0), gx = x0 + hx - (KS == 3 ? 1 : 0);
-      const int c = ci0 + hswz<RBH>(pix, slot) * EPP;
-      const T* src = zero;
-      if (pix < HPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.Ci)
-        src = in + (((long)b * a.H + gy) * a.W + gx) * a.ldin + c;
-      glds16(src, hbuf + i * 1024);
+      const bool ok = (unsigned)(y0 - ph + (h_yx[k] >> 16)) < (unsigned)a.H &&
+                      (unsigned)(x0 - ph + (h_yx[k] & 0xffff)) < (unsigned)a.W;
+      glds16(ok ? in + (unsigned)(h0 + h_off[k]) : zero, hbuf + i * 1024);
     }
   };
 
   auto multiply = [&](const char* lds_dy) {
     const char* lds_h = lds_dy + DBUF;
     if constexpr (BF) {
-      // k-step = 32 consecutive tile pixels; this wave takes steps wk, wk+NWK, ...
-#pragma unroll 1
-      for (int ks = wk; ks < NKS; ks += NWK) {
-        const int pk0 = ks * 32 + 8 * g + q;      // the row (pixel) this lane addresses in block kk=0
-        const int pk1 = pk0 + 4;                  // ... and in block kk=1
-        bf16x8 af[MT];
+      // k-step = 32 consecutive tile pixels; this wave takes steps wk, wk+NWK, ...: NST of them per
+      // tile.  A k-step falls into sub-steps (one kernel row, or one channel slice in the sliced
+      // 1x1 mode) of KS*MT MFMAs each.  Fragments are double-buffered in registers: while a
+      // sub-step multiplies, the transposing reads of the next one (and, at a k-step boundary, the
+      // next dy fragments) are issued between its MFMAs, so only the first sub-step of a tile
+      // waits for an LDS round trip.
+      constexpr int NST = NKS / NWK, SUB = KS * NSL, NU = NST * SUB, NTR = (KS == 3) ? 3 : 2;
+      static_assert(NKS % NWK == 0, "k-steps divide evenly over the K waves");
+      bf16x8 af[MT];
+      u32x2 t[2][NTR];
+      // Lane addresses of the reads of this wave's first k-step and kernel row 0; every other read
+      // of the tile is one of them plus a constant.
+      const int pkb = wk * 32 + 8 * g + q;                  // the pixel this lane addresses in block kk=0
+      const int rb = pkb / TW, cb = pkb - rb * TW;
+      int a_off[MT][2], t_off[NSL][NTR];
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-          af[m] = tr_read8(lds_dy + dy_row<RBD>(pk0) * RBD + dy_slot<RBD>(pk0, 2 * m + (p4 >> 1)) * 16 + (p4 & 1) * 8,
-                           lds_dy + dy_row<RBD>(pk1) * RBD + dy_slot<RBD>(pk1, 2 * m + (p4 >> 1)) * 16 + (p4 & 1) * 8);
-        const int r0 = pk0 / TW, c0_ = pk0 - r0 * TW;
-        const int sub = (p4 & 1) * 8;
-        // A lane's eight k-slots are eight consecutive pixels of one image row, so the three
-        // horizontal taps are the 8-pixel windows at offsets 0, 1, 2 of a 12-pixel run: three
-        // transposing reads per kernel row, the windows cut out of them in registers.
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int ky = 0; ky < KS; ++ky)
+        for (int h = 0; h < 2; ++h) {                       // block kk=1 is four pixels further on
+          const int pk = pkb + 4 * h;
+          a_off[m][h] = dy_row<RBD>(pk) * RBD + dy_slot<RBD>(pk, 2 * m + (p4 >> 1)) * 16 + (p4 & 1) * 8;
+        }
+      // A lane's eight k-slots are eight consecutive pixels of one image row, so the three
+      // horizontal taps are the 8-pixel windows at offsets 0, 1, 2 of a 12-pixel run: three
+      // transposing reads per kernel row, the windows cut out of them in registers.
 #pragma unroll
-          for (int sl = 0; sl < NSL; ++sl) {
-            const int slot = (wn * NSL + sl) * 2 + (p4 >> 1);
-            const int hr = (r0 + ky) * HW_ + c0_;
-            u32x2 t[KS == 3 ? 3 : 2];
+      for (int sl = 0; sl < NSL; ++sl)
 #pragma unroll
-            for (int i = 0; i < (KS == 3 ? 3 : 2); ++i) {
-              const int row = hr + 4 * i;
-              t[i] = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(
-                                                   short4v, lds_h + row * RBH + hswz<RBH>(row, slot) * 16 + sub)));
-            }
-            u32x4 win[KS];
-            win[0] = u32x4{t[0][0], t[0][1], t[1][0], t[1][1]};
-            if constexpr (KS == 3) {
-              win[1] = u32x4{__builtin_amdgcn_alignbit(t[0][1], t[0][0], 16),
-                             __builtin_amdgcn_alignbit(t[1][0], t[0][1], 16),
-                             __builtin_amdgcn_alignbit(t[1][1], t[1][0], 16),
-                             __builtin_amdgcn_alignbit(t[2][0], t[1][1], 16)};
-              win[2] = u32x4{t[0][1], t[1][0], t[1][1], t[2][0]};
-            }
+        for (int i = 0; i < NTR; ++i) {
+          const int hx = cb + 4 * i;
+          t_off[sl][i] = (rb * HW_ + hx) * RBH + hswz<RBH>(hx, (wn * NSL + sl) * 2 + (p4 >> 1)) * 16 + (p4 & 1) * 8;
+        }
+      auto load_a = [&](int st, int m) __attribute__((always_inline)) {
+        const int adv = st * NWK * 32 * RBD;                // k-steps are whole 16-pixel blocks apart
+        af[m] = tr_read8(lds_dy + a_off[m][0] + adv, lds_dy + a_off[m][1] + adv);
+      };
+      auto load_t = [&](int buf, int u) __attribute__((always_inline)) {
+        const int st = u / SUB, ky = (u % SUB) / NSL, sl = u % NSL;
+        const int adv = ((st * NWK * 32 / TW + ky) * HW_) * RBH;
 #pragma unroll
-            for (int kx = 0; kx < KS; ++kx) {
-              const bf16x8 bfr = __builtin_bit_cast(bf16x8, win[kx]);
+        for (int i = 0; i < NTR; ++i)
+          t[buf][i] = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                                    LDS_PTR(short4v, lds_h + t_off[sl][i] + adv)));
+      };
 #pragma unroll
-              for (int m = 0; m < MT; ++m)
-                acc[m][(ky * KS + kx) * NSL + sl] =
-                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr, acc[m][(ky * KS + kx) * NSL + sl], 0, 0, 0);
-            }
-          }
-      }
+      for (int m = 0; m < MT; ++m) load_a(0, m);
+      load_t(0, 0);
+      static_for<NU>([&](auto uc) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value;
+        constexpr int st = u / SUB, ky = (u % SUB) / NSL, sl = u % NSL, cur = u & 1;
+        // While this sub-step multiplies, the window reads of the next one go out behind its first
+        // MFMAs.  The dy fragments have one register set: in the k-step's last sub-step each is
+        // reloaded for the next k-step right behind its last MFMA; the MFMAs run row block by row
+        // block, so a reloaded fragment is first needed a sub-step's worth of MFMAs later.
+        constexpr bool more = u + 1 < NU, reload = (u % SUB == SUB - 1) && st + 1 < NST;
+        if constexpr (more) load_t(cur ^ 1, u + 1);
+        u32x4 win[KS];
+        win[0] = u32x4{t[cur][0][0], t[cur][0][1], t[cur][1][0], t[cur][1][1]};
+        if constexpr (KS == 3) {
+          win[1] = u32x4{__builtin_amdgcn_alignbit(t[cur][0][1], t[cur][0][0], 16),
+                         __builtin_amdgcn_alignbit(t[cur][1][0], t[cur][0][1], 16),
+                         __builtin_amdgcn_alignbit(t[cur][1][1], t[cur][1][0], 16),
+                         __builtin_amdgcn_alignbit(t[cur][2][0], t[cur][1][1], 16)};
+          win[2] = u32x4{t[cur][0][1], t[cur][1][0], t[cur][1][1], t[cur][2][0]};
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+          for (int kx = 0; kx < KS; ++kx)
+            acc[m][(ky * KS + kx) * NSL + sl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                af[m], __builtin_bit_cast(bf16x8, win[kx]), acc[m][(ky * KS + kx) * NSL + sl], 0, 0, 0);
+          if constexpr (reload) load_a(st + 1, m);
+        }
+        // issue order: first MFMA, window reads, rest of the row block, its reload, next row block ...
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (more) __builtin_amdgcn_sched_group_barrier(0x100, NTR, 0);
+        if constexpr (reload) {
+          if constexpr (KS > 1) __builtin_amdgcn_sched_group_barrier(0x008, KS - 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          static_for<MT - 1>([&](auto) __attribute__((always_inline)) {
+            __builtin_amdgcn_sched_group_barrier(0x008, KS, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          });
+        } else {
+          if constexpr (KS * MT > 1) __builtin_amdgcn_sched_group_barrier(0x008, KS * MT - 1, 0);
+        }
+      });
     } else {
       // k-step = 4 consecutive tile pixels; A[m=lane&15][k=lane>>4], B[k=lane>>4][n=lane&15]
 #pragma unroll 1
@@ -247,7 +311,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
           for (int kx = 0; kx < KS; ++kx) {
             const int hr = (r0 + ky) * HW_ + c0_ + kx;
-            const float bv = *reinterpret_cast<const float*>(lds_h + hr * RBH + hswz<RBH>(hr, byte >> 4) * 16 +
+            const float bv = *reinterpret_cast<const float*>(lds_h + hr * RBH + hswz<RBH>(c0_ + kx, byte >> 4) * 16 +
                                                              (byte & 15));
 #pragma unroll
             for (int m = 0; m < MT; ++m)
@@ -383,12 +447,14 @@ WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int dtype, int ks) {
   WgradPlan p;
   p.mt = (Co % 48 == 0) ? 3 : ((Co % 64 == 0 || Co > 48) ? 4 : (Co > 32 ? 3 : 2));
   p.tw = (W <= 16) ? 16 : 32;
-  // 64 input channels per workgroup when that wastes no padding, else 32
-  // Low-intensity shapes (flops per operand byte = 9*Co*Ci/(Co+Ci)) are bandwidth-bound: they
-  // also take 64-channel chunks, trading padded MFMA work for fewer passes over dy.
+  // 3x3: 32 input channels per workgroup (two waves across the channels, four along K); the
+  // 64-channel form only for 1x1 shapes, where it wastes no padding or the shape is bandwidth-bound
+  // (flops per operand byte = Co*Ci/(Co+Ci) small): fewer passes over dy for padded MFMA work.
   const bool low_intensity = 9.0 * Co * Ci / (Co + Ci) < 350.0;
-  p.nwn = (dtype == UNETK_BF16 && (Ci % 64 == 0 || (Ci > 256 && (Ci % 64) > 32) || (low_intensity && Ci > 32)))
-              ? 4 : 2;
+  p.nwn = 2;
+  if (ks == 1 && dtype == UNETK_BF16 &&
+      (Ci % 64 == 0 || (Ci > 256 && (Ci % 64) > 32) || (low_intensity && Ci > 32)))
+    p.nwn = 4;
   if (ks == 1 && dtype == UNETK_BF16 && Ci >= 64) p.nwn = 1;   // plain GEMM: 4 channel slices per wave
   p.nwk = 8 / p.nwn;
   p.tpix = dtype == UNETK_BF16 ? 256 : 128;
@@ -400,11 +466,25 @@ WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int dtype, int ks) {
   const int kci = p.nwn == 1 ? 64 : p.nwn * 16;
   p.Ci_pad = cdiv(Ci, kci) * kci;
   const int gxy = (p.Ci_pad / kci) * (p.Co_pad / (p.mt * 16));
-  int s = 768 / gxy;                       // one workgroup per CU: aim at ~3 rounds of 256
-  if (s > 256) s = 256;                    // bound the number of partial slabs
-  if (s < 1) s = 1;
-  if (s > p.ntiles) s = p.ntiles;
-  if (s >= 32) s &= ~7;                    // multiples of 8 enable the XCD-aware workgroup order
+  // Pixel split: one workgroup per CU at a time, so the grid should be a whole number of rounds of
+  // 256 (and at least two, when there are tiles enough); every split costs one more partial slab
+  // to write and read back.  Score = fill of the last round, discounted by the slab traffic
+  // relative to the multiply (at ~700 TFLOP/s and ~3 TB/s).
+  const double t_mul = 2.0 * B * H * W * ks * ks * (double)p.Ci_pad * p.Co_pad / 700e12;
+  const double t_slab = 8.0 * ks * ks * (double)p.Ci_pad * p.Co_pad / 3e12;
+  int s = 1;
+  double best = -1.0;
+  for (int c = 1; c <= 256 && c <= p.ntiles; c += (c < 32 ? 1 : 8)) {
+    const long wgs = (long)gxy * c;
+    const long rounds = (wgs + 255) / 256;
+    double score = (double)wgs / (256.0 * rounds) / (1.0 + c * t_slab / t_mul);
+    if (rounds < 2) score *= 0.8;
+    if ((c & 7) == 0) score *= 1.15;       // enables the XCD-aware workgroup order (shared tiles hit one L2)
+    if (score > best) {
+      best = score;
+      s = c;
+    }
+  }
   p.nsplit = s;
   return p;
 }
@@ -430,9 +510,9 @@ int launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t stream) {
     return UNETK_OK;                                                                                   \
   }
   WG_CASE(2, 16, 2) WG_CASE(2, 32, 2) WG_CASE(3, 16, 2) WG_CASE(3, 32, 2) WG_CASE(4, 16, 2) WG_CASE(4, 32, 2)
-  if constexpr (sizeof(T) == 2) {   // 64-channel chunks only fit LDS with 2-byte elements
+  if constexpr (sizeof(T) == 2 && KS == 1) {   // 64-channel chunks: bf16 1x1 only
     WG_CASE(2, 16, 4) WG_CASE(2, 32, 4) WG_CASE(3, 16, 4) WG_CASE(3, 32, 4) WG_CASE(4, 16, 4) WG_CASE(4, 32, 4)
-    if constexpr (KS == 1) {
+    {
       WG_CASE(2, 16, 1) WG_CASE(2, 32, 1) WG_CASE(3, 16, 1) WG_CASE(3, 32, 1) WG_CASE(4, 16, 1) WG_CASE(4, 32, 1)
     }
   }
@@ -461,6 +541,8 @@ int unetk_conv_wgrad(const void* in, int ldin, const void* dy, int lddy, float* 
   UNETK_CHECK_ARG(Ci % epp == 0 && Co % epp == 0 && ldin % epp == 0 && lddy % epp == 0,
                   "conv_wgrad: channels and strides must be multiples of %d", epp);
   UNETK_CHECK_ARG(((uintptr_t)in % 16) == 0 && ((uintptr_t)dy % 16) == 0, "conv_wgrad: misaligned pointer");
+  UNETK_CHECK_ARG((int64_t)B * H * W * (ldin > lddy ? ldin : lddy) < (1LL << 31),
+                  "conv_wgrad: tensors of 2^31 elements or more are not supported");
   refold_1x1(B, H, W, ks);
   const WgradPlan p = plan_wgrad(B, H, W, Ci, Co, dtype, ks);
   const int64_t need = unetk_conv_wgrad_workspace_bytes(B, H, W, Ci, Co, ks, dtype);
