@@ -154,29 +154,31 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const T* zero = reinterpret_cast<const T*>(conv_zero_page);
-  // DMA source addresses.  What depends on the lane and the piece but not on the tile or the chunk
-  // is computed once: for halo piece k of this wave the pixel's halo coordinates, its element
-  // offset from the halo's first pixel and its channel slot.  Issuing a piece then costs a few
-  // compares and one 64-bit add instead of divisions and multiplies between the MFMAs.
+  // DMA source addresses.  What depends on the lane and the piece but not on the chunk is computed
+  // once, one register a piece: the element offset of the lane's 16 bytes from the halo's first
+  // pixel, plus (in flags the compiler keeps as lane masks) whether the pixel lies inside the
+  // image.  The lane's channel slot is the same in every piece: pieces are 16 pixels apart and
+  // swz() looks at pixel bit 2 only.  Issuing a piece then costs two 32-bit operations and a
+  // select instead of divisions and multiplies between the MFMAs.
   constexpr int HPW = (HINSTR + 3) / 4;                 // halo pieces per wave (at most)
-  int h_rel[HPW], h_yx[HPW], h_slot[HPW];
+  const int slot0 = ((lane & 3) ^ swz(lane >> 2)) * EPP;
+  const unsigned rows_left = (KS == 3) ? 0u : (unsigned)((npix - p0 < 256) ? (npix - p0) : 256);
+  int hp_off[HPW];
+  bool hp_in[HPW];
 #pragma unroll
   for (int k = 0; k < (HDB ? HPW : 0); ++k) {
-    const int part = (wave + 4 * k) * 64 + lane;
-    const int pix = part >> 2;
-    h_slot[k] = ((part & 3) ^ swz(pix)) * EPP;
+    const int pix = (wave + 4 * k) * 16 + (lane >> 2);
     if (KS == 3) {
       const int hy = pix / HALO, hx = pix - hy * HALO;
-      h_rel[k] = (hy * a.W + hx) * a.ldin + h_slot[k];
-      h_yx[k] = (pix < HPIX) ? ((hy << 16) | hx) : (0x7fff << 16);   // rows past the halo never pass the test
+      hp_off[k] = (hy * a.W + hx) * a.ldin + slot0;
+      hp_in[k] = pix < HPIX && (unsigned)(y0 - 1 + hy) < (unsigned)a.H && (unsigned)(x0 - 1 + hx) < (unsigned)a.W;
     } else {
-      h_rel[k] = pix * a.ldin + h_slot[k];
-      h_yx[k] = pix;
+      hp_off[k] = pix * a.ldin + slot0;
+      hp_in[k] = (unsigned)pix < rows_left;
     }
   }
   // first halo pixel of the tile (may lie outside the image: only valid lanes add to it)
   const T* halo_base = (KS == 3) ? in + (((long)b * a.H + (y0 - 1)) * a.W + (x0 - 1)) * a.ldin : in + p0 * a.ldin;
-  const unsigned rows_left = (KS == 3) ? 0u : (unsigned)((npix - p0 < 256) ? (npix - p0) : 256);
   auto issue_halo = [&](int ch) {
     char* dst = lds + (RING3 ? ch % 3 : (HDB ? (ch & 1) : 0)) * HBUF;
     const int c0 = ch * KC;
@@ -202,18 +204,13 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
       }
       return;
     }
+    // (the chunk's offset is added to the lane's in 32 bits: the offsets stay one register each)
+    const bool chan_ok = slot0 < climit;
 #pragma unroll
     for (int k = 0; k < HPW; ++k) {
       const int i = wave + 4 * k;
       if (i < HINSTR) {
-        bool ok;
-        if (KS == 3) {
-          const unsigned gy = (unsigned)(y0 - 1 + (h_yx[k] >> 16)), gx = (unsigned)(x0 - 1 + (h_yx[k] & 0xffff));
-          ok = gy < (unsigned)a.H && gx < (unsigned)a.W && h_slot[k] < climit;
-        } else {
-          ok = (unsigned)h_yx[k] < rows_left && h_slot[k] < climit;
-        }
-        const T* src = ok ? base + h_rel[k] : zero;
+        const T* src = (hp_in[k] && chan_ok) ? halo_base + (unsigned)(hp_off[k] + c0) : zero;
         glds16(src, dst + i * 1024);
       }
     }
@@ -281,26 +278,12 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     auto open_phase = [&](int q, int vm_keep) {
       // q: the phase whose operands must have landed; afterwards the DMA of phase q+1 goes out
       switch (vm_keep) {
-#ifdef EXP_NOWAIT
-#define UNETK_WLB(N) case N: asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-#elif defined(EXP_NOBAR)
-#define UNETK_WLB(N) case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory"); break;
-#else
 #define UNETK_WLB(N) case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-#endif
         UNETK_WLB(1) UNETK_WLB(2) UNETK_WLB(3) UNETK_WLB(4) UNETK_WLB(5) UNETK_WLB(6) UNETK_WLB(7) UNETK_WLB(8)
-#ifdef EXP_NOWAIT
-        default: asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-#elif defined(EXP_NOBAR)
-        default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
-#else
         default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-#endif
 #undef UNETK_WLB
       }
-#if !defined(EXP_NODMA) && !defined(EXP_NOW)
       if (q + 1 < nphase) issue_w(q + 1);
-#endif
     };
     auto chunk = [&](auto parc, int ch) {
       constexpr int PAR = decltype(parc)::value;
@@ -315,11 +298,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
               // q opens chunk ch+1: its halo was drained at the previous barrier
               open_phase(q, 0);
               halo_fly = ch + 2 < a.nchunks;
-#if !defined(EXP_NODMA) && !defined(EXP_NOH)
               if (halo_fly) issue_halo(ch + 2);
-#else
-              halo_fly = false;
-#endif
             } else {
               open_phase(q, (ky == 0 && halo_fly) ? my_halo : 0);
             }
@@ -761,6 +740,8 @@ int unetk_conv_fwd_fused(const void* in, int ldin, const void* wpacked, void* ou
     UNETK_CHECK_ARG(ldout >= Co, "conv_fwd: stride smaller than channel count");
   }
   UNETK_CHECK_ARG(ldin >= Ci, "conv_fwd: stride smaller than channel count");
+  UNETK_CHECK_ARG((int64_t)W * ldin * 20 + ldin < (1LL << 31) && 256LL * ldin < (1LL << 31),
+                  "conv_fwd: a halo of the input spans 2^31 elements or more");
   UNETK_CHECK_ARG(((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)wpacked % 16) == 0,
                   "conv_fwd: pointers must be 16-byte aligned");
   UNETK_CHECK_ARG(resid == nullptr || (ldres % epp == 0 && ((uintptr_t)resid % 16) == 0),
