@@ -245,6 +245,17 @@ int unetk_patch_gather(const float* feats, int nvar, const float* labels, const 
                        const int* pos, const int* flips, int n, int P, int sanitize, float* out_f, float* out_l,
                        float* out_w, unetk_stream_t stream);
 
+/* ---- Gaussian low-pass of a float64 grid (long-wavelength background) -------------------
+ * data_preparation.py:392-414 (apply_gaussian_filter: NaN -> 0, scipy.ndimage.gaussian_filter with
+ * mode='reflect', NaN restored) is two passes of unetk_gauss_rows_f64 (which filters along the
+ * contiguous axis) around two transposes.  wpad: the 2*radius+1 correlation weights followed by
+ * zeros up to a multiple of 16 entries.  zero_nan: treat NaN inputs as 0.  nan_src (rows x cols,
+ * or null): where it holds NaN the output is NaN.  in and out must not alias. */
+int unetk_gauss_rows_max_radius(void);
+int unetk_gauss_rows_f64(const double* in, double* out, const double* nan_src, int rows, int cols,
+                         const double* wpad, int radius, int zero_nan, unetk_stream_t stream);
+int unetk_transpose_f64(const double* in, double* out, int rows, int cols, unetk_stream_t stream);
+
 /* ---- validation metrics as streaming reductions ---------------------------------------
  * enhanced_training_multi_loss.py:883-889 (np.corrcoef over the concatenated validation set),
  * predict.py:188-200 (MSE, MAE, Pearson r).  state: 8 doubles on the device, zeroed by the

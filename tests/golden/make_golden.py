@@ -26,7 +26,7 @@ REF = "/root/reference"
 sys.path.insert(0, REPO)
 sys.dont_write_bytecode = True
 
-from oracle import loss_oracle, patch_oracle, swin_oracle, tile_oracle, unet_oracle  # noqa: E402
+from oracle import filter_oracle, loss_oracle, patch_oracle, swin_oracle, tile_oracle, unet_oracle  # noqa: E402
 from oracle import weights as W  # noqa: E402
 
 
@@ -418,10 +418,39 @@ def gen_patch(etml):
     print("patch.npz", len(out), "entries")
 
 
+FILTER_CASES = [  # name, lat, lon, sigma_lat, sigma_lon, NaN fraction, seed
+    ("small", 40, 56, 2.5, 3.25, 0.05, 3),
+    ("wide_sigma", 48, 300, 1.0, 20.0, 0.0, 4),       # radius 80 > lat extent is not hit; lon reflects deep
+    ("short_axis", 7, 90, 6.0, 2.0, 0.1, 5),          # radius 24 > 7 rows: the reflection wraps more than once
+]
+
+
+def gen_filter():
+    """Gaussian low-pass of the data preparation (data_preparation.py:392-414), run through the reference's own
+    method with a minimal stand-in for the xarray container it wraps the result in."""
+    import data_preparation as dp
+
+    class DA:
+        def __init__(self, values, coords=None, dims=None, name=None):
+            self.values, self.coords, self.dims, self.name, self.attrs = values, coords, dims, name, {}
+    dp.xr.DataArray = DA
+    out = {}
+    for name, lat, lon, s_lat, s_lon, nan_frac, seed in FILTER_CASES:
+        x = filter_oracle.synthetic_field(lat, lon, nan_frac, seed)
+        ref = dp.EnhancedBathymetryProcessor.apply_gaussian_filter(None, DA(x, {}, ("lat", "lon"), "bathy"), s_lat, s_lon).values
+        mine = filter_oracle.apply_gaussian_filter(x, s_lat, s_lon)
+        assert np.array_equal(np.isnan(ref), np.isnan(mine)), name
+        err = np.nanmax(np.abs(ref - mine)) / np.nanmax(np.abs(ref))
+        assert err < 1e-13, (name, err)
+        out[name] = ref
+    np.savez_compressed(os.path.join(HERE, "filter.npz"), **out)
+    print("filter.npz", len(out), "entries")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     tr, etml, swin, lap = import_reference()
-    which = sys.argv[1:] or ["unet", "loss", "tile", "swin", "step", "patch"]
+    which = sys.argv[1:] or ["unet", "loss", "tile", "swin", "step", "patch", "filter"]
     if "unet" in which:
         gen_unet(tr)
     if "loss" in which:
@@ -434,3 +463,5 @@ if __name__ == "__main__":
         gen_step(etml)
     if "patch" in which:
         gen_patch(etml)
+    if "filter" in which:
+        gen_filter()

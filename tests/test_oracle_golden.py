@@ -208,3 +208,25 @@ def test_patch_oracle_matches_golden(golden, case):
     assert 0 < len(got) < int(g[name + ".ncand"])
     sums = np.array([[a.astype(np.float64).sum() for a in patch_oracle.dataset_item(p)] for p in got])
     assert np.array_equal(sums, g[name + ".sums"])
+
+
+FILTER_CASES = [("small", 40, 56, 2.5, 3.25, 0.05, 3), ("wide_sigma", 48, 300, 1.0, 20.0, 0.0, 4),
+                ("short_axis", 7, 90, 6.0, 2.0, 0.1, 5)]
+
+
+@pytest.mark.parametrize("case", FILTER_CASES, ids=[c[0] for c in FILTER_CASES])
+def test_filter_oracle_matches_golden_and_scipy(golden, case):
+    """Gaussian low-pass (data_preparation.py:392-414): the restatement against the fixture frozen from the
+    reference's method, and against the reference's dependency (scipy.ndimage) called directly."""
+    from oracle import filter_oracle
+    from scipy.ndimage import gaussian_filter
+    name, lat, lon, s_lat, s_lon, nan_frac, seed = case
+    x = filter_oracle.synthetic_field(lat, lon, nan_frac, seed)
+    got = filter_oracle.apply_gaussian_filter(x, s_lat, s_lon)
+    gold = golden("filter")[name]
+    assert np.array_equal(np.isnan(got), np.isnan(gold))
+    scale = np.nanmax(np.abs(gold))
+    assert np.nanmax(np.abs(got - gold)) <= 1e-13 * scale
+    direct = gaussian_filter(np.nan_to_num(x, nan=0.0), sigma=[s_lat, s_lon], mode="reflect")
+    m = ~np.isnan(x)
+    assert np.max(np.abs(direct[m] - got[m])) <= 1e-13 * scale

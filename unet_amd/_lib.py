@@ -48,6 +48,9 @@ _SIGNATURES = {
     "unetk_patch_gather": (I, [P, I, P, P, I, I, P, P, I, I, I, P, P, P, P]),
     "unetk_metrics_num_partials": (I, [L]),
     "unetk_metrics_update": (I, [P, P, L, P, P, P]),
+    "unetk_gauss_rows_max_radius": (I, []),
+    "unetk_gauss_rows_f64": (I, [P, P, P, I, I, P, I, I, P]),
+    "unetk_transpose_f64": (I, [P, P, I, I, P]),
     "unetk_nchw_to_nhwc": (I, [P, P, I, I, I, I, I, I, P]),
     "unetk_nhwc_to_nchw": (I, [P, I, P, I, I, I, I, I, P]),
     "unetk_bn_finalize": (I, [P, I, I, L, P, P, F, F, P, P, P, P, P, P, P]),
