@@ -117,3 +117,32 @@ def test_full_size_properties():
     be.accumulate(ones, wk, slot, 0, nti * nti, nti, nti, P, S, acc, cnt, 0, G)
     out = be.normalize(acc, cnt)
     assert float((out - 3.25).abs().max()) < 1e-5 and float(cnt.min()) > 0
+
+
+def test_load_model_and_save_prediction(tmp_path):
+    """large_area_predictor.py:83-106 and :300-311: both checkpoint layouts the reference accepts load into the
+    same weights; a file that is not a checkpoint yields None; the NetCDF file reads back what was written."""
+    from scipy.io import netcdf_file
+    from unet_amd.predictor import LargeAreaPredictor
+    cfg = cfg_for(32, 16)
+    cfg.IN_CHANNELS, cfg.OUT_CHANNELS, cfg.INIT_FEATURES = 4, 1, 8
+    p = LargeAreaPredictor(cfg)
+    sd = W.fill_state_dict(W.unet_template(4, 1, 8), seed=42)
+    torch.save(sd, tmp_path / "bare.pth")
+    torch.save({"model_state_dict": sd, "epoch": 3, "val_loss": 0.5}, tmp_path / "wrapped.pth")
+    (tmp_path / "junk.pth").write_bytes(b"not a checkpoint")
+    a, b = p.load_model(str(tmp_path / "bare.pth")), p.load_model(str(tmp_path / "wrapped.pth"))
+    assert a is not None and b is not None and not a.training
+    assert next(a.parameters()).is_cuda
+    for k, v in sd.items():
+        assert torch.equal(a.state_dict()[k].cpu(), v) and torch.equal(b.state_dict()[k].cpu(), v)
+    assert p.load_model(str(tmp_path / "junk.pth")) is None
+    assert p.load_model(str(tmp_path / "absent.pth")) is None
+    feats = toy_features(80, 72, 3)
+    ds = _DS(feats)
+    out = p.predict_large_area(a, ds)
+    path = p.save_prediction(out, ds, "baseline")
+    assert path.endswith("large_area_prediction_baseline.nc")
+    with netcdf_file(path, "r", mmap=False) as nc:
+        assert np.array_equal(nc.variables["prediction_baseline"][:], out)
+        assert np.array_equal(nc.variables["lat"][:], np.arange(80)) and np.array_equal(nc.variables["lon"][:], np.arange(72))

@@ -105,6 +105,47 @@ class LargeAreaPredictor:
         k = np.exp(-0.5 * ((x - (center - 0.5)) ** 2 + (y - (center - 0.5)) ** 2) / sigma ** 2)
         return k.astype(np.float32)
 
+    # ------------------------------------------------------------------ checkpoints and results
+    def load_model(self, model_path: str, device: Optional[torch.device] = None, compute_dtype=torch.bfloat16):
+        """large_area_predictor.py:83-106: build ``OptimizedUNet(IN_CHANNELS, OUT_CHANNELS, INIT_FEATURES)``,
+        load ``checkpoint['model_state_dict']`` (or the bare state dict), eval mode; ``None`` on any failure,
+        as the reference.  Checkpoints are read with ``weights_only=True``: a file that pickles arbitrary
+        objects next to the tensors is refused rather than executed (and yields ``None``)."""
+        from .unet import OptimizedUNet
+        try:
+            ckpt = torch.load(model_path, map_location="cpu", weights_only=True)
+            model = OptimizedUNet(in_channels=self.config.IN_CHANNELS, out_channels=self.config.OUT_CHANNELS,
+                                  init_features=self.config.INIT_FEATURES, compute_dtype=compute_dtype)
+            model.load_state_dict(ckpt["model_state_dict"] if "model_state_dict" in ckpt else ckpt)
+            if device is None:
+                device = torch.device("cuda", torch.cuda.current_device())
+            model.to(device)
+            model.eval()
+            return model
+        except Exception:
+            return None
+
+    def save_prediction(self, prediction: np.ndarray, features, model_name: str) -> str:
+        """large_area_predictor.py:300-311: ``large_area_prediction_<model_name>.nc`` in OUTPUT_DIR with the
+        variable ``prediction_<model_name>`` on the (lat, lon) coordinates of ``features``.  Written as
+        NetCDF-3 classic through scipy.io (xarray.open_dataarray reads it back)."""
+        from scipy.io import netcdf_file
+        path = os.path.join(self.config.OUTPUT_DIR, f"large_area_prediction_{model_name}.nc")
+        lat = np.asarray(getattr(features.lat, "values", features.lat), dtype=np.float64)
+        lon = np.asarray(getattr(features.lon, "values", features.lon), dtype=np.float64)
+        pred = np.asarray(prediction, dtype=np.float32)
+        if pred.shape != (len(lat), len(lon)):
+            raise ValueError(f"prediction {pred.shape} does not match the coordinates ({len(lat)}, {len(lon)})")
+        with netcdf_file(path, "w") as nc:
+            nc.createDimension("lat", len(lat))
+            nc.createDimension("lon", len(lon))
+            vlat = nc.createVariable("lat", "f8", ("lat",))
+            vlon = nc.createVariable("lon", "f8", ("lon",))
+            vlat[:], vlon[:] = lat, lon
+            v = nc.createVariable(f"prediction_{model_name}", "f4", ("lat", "lon"))
+            v[:] = pred
+        return path
+
     # ------------------------------------------------------------------ core
     def predict_large_area(self, model, features, device: Optional[torch.device] = None) -> np.ndarray:
         P = int(self.config.PATCH_SIZE)
