@@ -444,11 +444,14 @@ template <typename T>
 __global__ __launch_bounds__(64) void window_attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                              const float* __restrict__ table, AttnGeom g) {
   using L = AttnLds<T>;
-  __shared__ __attribute__((aligned(16))) char Qs[NTOK * L::R32];
-  __shared__ __attribute__((aligned(16))) char Ks[NTOK * L::R32];
+  // (one wave per workgroup: P is written over Q and K, which are dead once S is in registers)
+  static_assert(NTOK * L::R64 <= 2 * NTOK * L::R32, "P fits the storage of Q and K");
+  __shared__ __attribute__((aligned(16))) char QK[2 * NTOK * L::R32];
   __shared__ __attribute__((aligned(16))) char Vt[HD * L::R64];
-  __shared__ __attribute__((aligned(16))) char Ps[NTOK * L::R64];
   __shared__ float tbl[(2 * WS - 1) * (2 * WS - 1)];
+  char* const Qs = QK;
+  char* const Ks = QK + NTOK * L::R32;
+  char* const Ps = QK;
   const int lane = threadIdx.x;
   const int nwx = g.We / WS, nwy = g.He / WS;
   int t = blockIdx.x;
@@ -505,17 +508,24 @@ __global__ __launch_bounds__(64) void window_attn_bwd_kernel(const T* __restrict
                                                              T* __restrict__ dqkv, const float* __restrict__ table,
                                                              float* __restrict__ dtable_partials, AttnGeom g) {
   using L = AttnLds<T>;
-  __shared__ __attribute__((aligned(16))) char Qs[NTOK * L::R32];
-  __shared__ __attribute__((aligned(16))) char Ks[NTOK * L::R32];
-  __shared__ __attribute__((aligned(16))) char Vs[NTOK * L::R32];
-  __shared__ __attribute__((aligned(16))) char Ds[NTOK * L::R32];
+  // One wave per workgroup, so the LDS footprint IS the occupancy: buffers share storage by
+  // lifetime.  Q, K (rows) are dead once S = QK^T is in registers: P^T, later dS, lives there.
+  // V, dO (rows) are dead after dP = dO V^T: dS^T lives there.  (One wave: LDS operations complete
+  // in issue order, so reuse needs no more than the barriers already between the phases.)
+  constexpr int ROWS2 = 2 * NTOK * L::R32;
+  static_assert(NTOK * L::R64 <= ROWS2, "a 64x64 tile fits the storage of two 64x32 operands");
+  __shared__ __attribute__((aligned(16))) char bufA[ROWS2];
+  __shared__ __attribute__((aligned(16))) char bufB[ROWS2];
   __shared__ __attribute__((aligned(16))) char Qt[HD * L::R64];
   __shared__ __attribute__((aligned(16))) char Kt[HD * L::R64];
   __shared__ __attribute__((aligned(16))) char Dt[HD * L::R64];
-  __shared__ __attribute__((aligned(16))) char PA[NTOK * L::R64];   // P^T, later dS
-  __shared__ __attribute__((aligned(16))) char PB[NTOK * L::R64];   // dS^T
-  __shared__ float dSf[NTOK][NTOK + 1];
   __shared__ float tbl[(2 * WS - 1) * (2 * WS - 1)];
+  char* const Qs = bufA;
+  char* const Ks = bufA + NTOK * L::R32;
+  char* const PA = bufA;                       // P^T, later dS
+  char* const Vs = bufB;
+  char* const Ds = bufB + NTOK * L::R32;
+  char* const PB = bufB;                       // dS^T
   const int lane = threadIdx.x;
   const int cl = lane & 15, pg = lane >> 4;
   const int nwx = g.We / WS, nwy = g.He / WS;
@@ -597,7 +607,6 @@ __global__ __launch_bounds__(64) void window_attn_bwd_kernel(const T* __restrict
         const float v = dp[m][n][r];
         reinterpret_cast<T*>(PA + i * L::R64)[j] = from_f32<T>(v);
         reinterpret_cast<T*>(PB + j * L::R64)[i] = from_f32<T>(v);
-        dSf[i][j] = v;
       }
   __syncthreads();
   {   // dQ[query][d] = scale * sum_key dS[query][key] * K^T[d][key];  dK[key][d] = scale * sum_query dS^T * Q^T
@@ -621,6 +630,7 @@ __global__ __launch_bounds__(64) void window_attn_bwd_kernel(const T* __restrict
       }
   }
   // bias-table gradient of this (window, head): bin (dy,dx) sums dS[i][j] over yi-yj=dy, xi-xj=dx
+  // (dS as stored for the two products above, i.e. rounded to T)
   for (int bin = lane; bin < 225; bin += 64) {
     const int dy = bin / 15 - 7, dx = bin % 15 - 7;
     float acc = 0.f;
@@ -630,7 +640,7 @@ __global__ __launch_bounds__(64) void window_attn_bwd_kernel(const T* __restrict
       for (int xj = 0; xj < WS; ++xj) {
         const int xi = xj + dx;
         if (xi < 0 || xi >= WS) continue;
-        acc += dSf[yi * WS + xi][yj * WS + xj];
+        acc += to_f32(reinterpret_cast<const T*>(PA + (yi * WS + xi) * L::R64)[yj * WS + xj]);
       }
     }
     dtable_partials[(long)blockIdx.x * 225 + bin] = acc;
