@@ -46,6 +46,12 @@ int unetk_conv_pick_bn(int Co);
 int64_t unetk_conv_packed_elems(int Co, int Ci, int ks, int bn, int dtype);
 int unetk_conv_pack_weight(const float* w, void* packed, int Co, int Ci, int ks, int bn, int dtype,
                            int transpose, unetk_stream_t stream);
+/* Many weights in one launch.  jobs (device): 9 int64 per job = fp32 source pointer, destination
+ * offset in elements from dst_base (16-byte aligned), Co, Ci, ks, bn, ceil(packed Ci / channels-per-chunk), transpose, packed
+ * element count (unetk_conv_packed_elems); Co/Ci are the SOURCE tensor's.  blocks (device): per
+ * workgroup two int32 = (job, 256-element block inside the job); nblocks of them. */
+int unetk_conv_pack_weights(const int64_t* jobs, const int* blocks, int nblocks, void* dst_base, int dtype,
+                            unetk_stream_t stream);
 int unetk_conv_num_tiles(int B, int H, int W, int ks);
 /* out = act((conv(in, w)) * ep_scale + ep_shift) [* resid_keep[b] + resid].
  * stats (nullable): [unetk_conv_num_tiles][2][Co] per-tile sum / sum of squares of the raw

@@ -622,6 +622,42 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
   dst[idx] = from_f32<T>(v);
 }
 
+// Many weights in one launch (a training step re-packs every conv / linear weight, forward and
+// data-gradient form: dozens of tiny launches otherwise).  jobs: 9 int64 per job = source pointer,
+// destination offset (elements from dst_base), Co, Ci, ks, bn, chunks, transpose, packed elements;
+// blocks: per workgroup (job, 256-element block inside the job).
+template <typename T>
+__global__ void pack_weights_batched_kernel(const long* __restrict__ jobs, const int* __restrict__ blocks,
+                                            T* __restrict__ dst_base, int kc) {
+  const int job = blocks[2 * blockIdx.x], blk = blocks[2 * blockIdx.x + 1];
+  const long* j = jobs + 9L * job;
+  const float* w = reinterpret_cast<const float*>(j[0]);
+  T* dst = dst_base + j[1];
+  const int Co = (int)j[2], Ci = (int)j[3], ks = (int)j[4], bn = (int)j[5], nchunks = (int)j[6], transpose = (int)j[7];
+  const long total = j[8];
+  const long idx = (long)blk * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int taps = ks * ks;
+  long t = idx;
+  const int k = t % kc;
+  t /= kc;
+  const int row = t % bn;
+  t /= bn;
+  const int tap = t % taps;
+  t /= taps;
+  const int ch = t % nchunks;
+  const int nb = t / nchunks;
+  const int n = nb * bn + row;
+  const int c = ch * kc + k;
+  float v = 0.f;
+  if (!transpose) {
+    if (n < Co && c < Ci) v = w[((long)n * Ci + c) * taps + tap];
+  } else {
+    if (n < Ci && c < Co) v = w[((long)c * Ci + n) * taps + (taps - 1 - tap)];
+  }
+  dst[idx] = from_f32<T>(v);
+}
+
 template <typename T, int KS>
 int launch_conv(ConvArgs a, int bn, hipStream_t stream) {
   const long npix = (long)a.B * a.H * a.W;
@@ -702,6 +738,20 @@ int unetk_conv_pack_weight(const float* w, void* packed, int Co, int Ci, int ks,
   else
     hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(grid), dim3(256), 0, stream, w, (float*)packed,
                        Co, Ci, ks, bn, kc, nchunks, transpose, total);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_conv_pack_weights(const int64_t* jobs, const int* blocks, int nblocks, void* dst_base, int dtype,
+                            hipStream_t stream) {
+  UNETK_CHECK_ARG(jobs && blocks && nblocks > 0 && dst_base && ((uintptr_t)dst_base % 16) == 0, "conv_pack_weights: bad arguments");
+  UNETK_CHECK_ARG(dtype == UNETK_F32 || dtype == UNETK_BF16, "conv_pack_weights: bad dtype %d", dtype);
+  if (dtype == UNETK_BF16)
+    hipLaunchKernelGGL(pack_weights_batched_kernel<bf16>, dim3(nblocks), dim3(256), 0, stream,
+                       reinterpret_cast<const long*>(jobs), blocks, (bf16*)dst_base, kc_of(dtype));
+  else
+    hipLaunchKernelGGL(pack_weights_batched_kernel<float>, dim3(nblocks), dim3(256), 0, stream,
+                       reinterpret_cast<const long*>(jobs), blocks, (float*)dst_base, kc_of(dtype));
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }

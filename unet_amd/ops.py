@@ -69,6 +69,73 @@ class PackedConv:
         call("unetk_conv_pack_weight", ptr(w), ptr(self.data), Co, Ci, ks, self.bn, dtype_code(dt),
              1 if transpose else 0, stream())
 
+    @classmethod
+    def _view(cls, meta, flat, dt):
+        """A pack that lives inside a buffer shared by a batch of packs (see pack_many)."""
+        pCo, pCi, ks, bn, o, n = meta
+        pk = cls.__new__(cls)
+        pk.bn, pk.Co, pk.Ci, pk.ks, pk.dt = bn, pCo, pCi, ks, dt
+        pk.data = flat[o:o + n]
+        return pk
+
+
+_PACK_TABLES = {}      # (pointers, shapes) -> (jobs, blocks, nblocks, pinned host copies); a handful of entries
+
+
+def pack_many(weights, dt):
+    """Pack several weights with ONE launch.  weights: list of (fp32 GPU tensor (Co, Ci[, k, k]), transpose);
+    returns the list of PackedConv (views of one buffer).  The device-side job table depends on the
+    source addresses and shapes only, and parameters do not move: a training step re-uses it (a new
+    one goes up from pinned memory without blocking the host)."""
+    if not weights:
+        return []
+    import numpy as np
+    # fast path: the same parameters as last time (addresses, shapes, forms)
+    light = (tuple((w.data_ptr(), w.shape, tr, w.dtype, w.is_contiguous()) for w, tr in weights), dt)
+    plan = _PACK_TABLES.get(light)
+    if plan is not None:
+        metas, off, hit = plan
+        flat = torch.empty(off, dtype=dt, device=weights[0][0].device)
+        call("unetk_conv_pack_weights", ptr(hit[0]), ptr(hit[1]), hit[2], ptr(flat), dtype_code(dt), stream())
+        return [PackedConv._view(m, flat, dt) for m in metas]
+    lib = _lib.load()
+    kc = 32 if dt == torch.bfloat16 else 16
+    metas, srcs, rows, off = [], [], [], 0
+    for w, transpose in weights:
+        _require_cuda(w, "weight")
+        if w.dim() == 2:
+            w = w.view(w.shape[0], w.shape[1], 1, 1)
+        w = w.detach()
+        if w.dtype != torch.float32 or not w.is_contiguous():
+            w = w.contiguous().float()
+        Co, Ci, ks, _ = w.shape
+        pCo, pCi = (Ci, Co) if transpose else (Co, Ci)
+        bn = lib.unetk_conv_pick_bn(pCo)
+        n = lib.unetk_conv_packed_elems(pCo, pCi, ks, bn, dtype_code(dt))
+        metas.append((pCo, pCi, ks, bn, off, n))
+        srcs.append(w)
+        rows.append((w.data_ptr(), off, Co, Ci, ks, bn, -(-pCi // kc), 1 if transpose else 0, n))
+        off += -(-n // 8) * 8                     # keep every pack 16-byte aligned
+    dev = srcs[0].device
+    key = (tuple(rows), dt, dev)
+    hit = _PACK_TABLES.get(key)
+    if hit is None:
+        jobs_h = torch.from_numpy(np.asarray(rows, dtype=np.int64).reshape(-1)).pin_memory()
+        nblk = np.asarray([-(-r[8] // 256) for r in rows], dtype=np.int64)
+        job_of = np.repeat(np.arange(len(rows), dtype=np.int32), nblk)
+        first = np.repeat(np.cumsum(nblk) - nblk, nblk)
+        blocks = np.stack([job_of, (np.arange(int(nblk.sum())) - first).astype(np.int32)], 1).astype(np.int32)
+        blocks_h = torch.from_numpy(np.ascontiguousarray(blocks).reshape(-1)).pin_memory()
+        hit = (jobs_h.to(dev, non_blocking=True), blocks_h.to(dev, non_blocking=True), int(nblk.sum()), jobs_h, blocks_h)
+        if len(_PACK_TABLES) >= 16:
+            _PACK_TABLES.pop(next(iter(_PACK_TABLES)))
+        _PACK_TABLES[key] = hit
+    if all(w.dtype == torch.float32 and w.is_contiguous() for w, _ in weights):    # no temporaries among the sources
+        _PACK_TABLES[light] = (metas, off, hit)
+    flat = torch.empty(off, dtype=dt, device=dev)
+    call("unetk_conv_pack_weights", ptr(hit[0]), ptr(hit[1]), hit[2], ptr(flat), dtype_code(dt), stream())
+    return [PackedConv._view(m, flat, dt) for m in metas]
+
 
 def conv_fwd(x: torch.Tensor, pw: PackedConv, Ci: Optional[int] = None, Co: Optional[int] = None,
              out: Optional[torch.Tensor] = None, want_stats: bool = False, scale=None, shift=None,

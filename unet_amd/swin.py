@@ -195,9 +195,43 @@ class SwinUNet(nn.Module):
             return _forward(self, x, None, None)
 
 
+# ------------------------------------------------------------------ packed weights
+# The packed forms of every Linear / Conv2d weight are made by ONE launch at the start of a forward
+# (forward form, and for training the data-gradient form) and looked up by the parameter's address
+# where a layer needs them; anything not found there (a reshaped copy) is packed on the spot.
+_POOL: Dict = {}
+
+
+def _prepack(model, dt, training):
+    global _POOL
+    ws = []
+    for m in model.modules():
+        if isinstance(m, (nn.Linear, nn.Conv2d)):
+            w = m.weight
+            if w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and \
+                    (w.dim() == 2 or (w.shape[2] == w.shape[3] and w.shape[2] in (1, 3))):
+                ws.append(w)
+    forms = (False, True) if training else (False,)
+    packs = ops.pack_many([(w, tr) for tr in forms for w in ws], dt)
+    pool = {}
+    for i, tr in enumerate(forms):
+        for j, w in enumerate(ws):
+            pool[(w.data_ptr(), tr)] = (packs[i * len(ws) + j], w.shape[0], w.shape[1], 1 if w.dim() == 2 else w.shape[2], dt)
+    _POOL = pool
+    return pool
+
+
+def _packed(w, dt, transpose=False):
+    hit = _POOL.get((w.data_ptr(), bool(transpose)))
+    ks = 1 if w.dim() == 2 else w.shape[2]
+    if hit is not None and hit[1:] == (w.shape[0], w.shape[1], ks, dt):
+        return hit[0]
+    return ops.PackedConv(w, dt, transpose=transpose)
+
+
 # ------------------------------------------------------------------ building blocks
 def _linear(x, w, b, dt, act=0, resid=None, keep=None, out=None):
-    return ops.conv_fwd(x, ops.PackedConv(w, dt), scale=None, shift=b, act=act, resid=resid, resid_keep=keep,
+    return ops.conv_fwd(x, _packed(w, dt), scale=None, shift=b, act=act, resid=resid, resid_keep=keep,
                         out=out)[0]
 
 
@@ -207,7 +241,7 @@ def _linear_bwd(x, dy, w, dt, grads, wname, bname, need_dx=True):
     if bname is not None:
         grads[bname] = ops.channel_sum(dy, Co)
     if need_dx:
-        return ops.conv_fwd(dy, ops.PackedConv(w.view(Co, Ci), dt, transpose=True))[0]
+        return ops.conv_fwd(dy, _packed(w.view(Co, Ci), dt, transpose=True))[0]
     return None
 
 
@@ -281,7 +315,7 @@ def _block_bwd(blk, pre, ctx, dx2, dt, grads):
 
 def _conv_bn_relu_fwd(conv, bn, t, dt, training, save, tag):
     """Conv3x3 -> BatchNorm2d -> ReLU.  A conv bias in front of BatchNorm only moves running_mean."""
-    pk = ops.PackedConv(conv.weight, dt)
+    pk = _packed(conv.weight, dt)
     if not training:
         sc, sh = ops.bn_fold_eval(bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.bias, bn.eps)
         return ops.conv_fwd(t, pk, scale=sc, shift=sh, act=1)[0]
@@ -307,7 +341,7 @@ def _conv_bn_relu_bwd(conv, bn, tag, ctx, g, dt, grads, need_dx=True):
     if conv.bias is not None:
         grads[cname + ".bias"] = torch.zeros_like(conv.bias)      # exactly 0 in front of BatchNorm
     if need_dx:
-        return ops.conv_fwd(dy, ops.PackedConv(conv.weight, dt, transpose=True))[0]
+        return ops.conv_fwd(dy, _packed(conv.weight, dt, transpose=True))[0]
     return None
 
 
@@ -323,7 +357,7 @@ def _decoder_fwd(dec, pre, x, skip, dt, training, save):
     resized = None
     if has_skip:
         if skip.shape[1:3] == (2 * h, 2 * w):
-            ops.conv_fwd(skip, ops.PackedConv(dec.skip_projection.weight, dt), out=cat[..., up:])
+            ops.conv_fwd(skip, _packed(dec.skip_projection.weight, dt), out=cat[..., up:])
         else:       # bilinear resize of the projected skip to the upsampled size (:526-529)
             sp = _linear(skip, dec.skip_projection.weight.view(up, -1), None, dt)
             resized = sp.shape[1:3]
@@ -354,7 +388,7 @@ def _decoder_head_bwd(dec, pre, ctx, dcat, dt, grads):
         if resized is not None:
             dsp = ops.upsample_bwd(dsp.contiguous(), up, resized[0], resized[1])
         grads[pre + "skip_projection.weight"] = ops.conv_wgrad(skip, dsp, wsk.shape[1], up, 1).view(wsk.shape)
-        dskip = ops.conv_fwd(dsp, ops.PackedConv(wsk, dt, transpose=True))[0]
+        dskip = ops.conv_fwd(dsp, _packed(wsk, dt, transpose=True))[0]
     return dx, dskip
 
 
@@ -362,6 +396,9 @@ def _forward(model, x, drop_path, save):
     """Whole network.  save=None: inference (BatchNorm folded, nothing kept)."""
     dt = model.compute_dtype
     training = save is not None
+    pool = _prepack(model, dt, training)
+    if training:
+        save.append(("packs", pool))
     ps = model.patch_size_val
     E = model.embed_dim_val
     tok_in = ops.patchify(x.detach(), ps, dt)
@@ -419,8 +456,12 @@ class _SwinTrainFn(torch.autograd.Function):
         dskips: Dict[int, torch.Tensor] = {}
         g = None
         pending_skip = None
+        global _POOL
+        _POOL = save[0][1]              # the packs made by this step's forward
         for rec in reversed(save):
             kind = rec[0]
+            if kind == "packs":
+                continue
             if kind == "head":
                 fc = model.final_conv
                 g, dw, db = ops.head1x1_bwd(rec[1], fc[3].weight, dout)
@@ -458,7 +499,7 @@ class _SwinTrainFn(torch.autograd.Function):
                 grads["patch_embed.bias"] = ops.channel_sum(dt0, E)
                 g = None
                 if ctx.need_dx:
-                    dtok = ops.conv_fwd(dt0, ops.PackedConv(wpe, dt, transpose=True))[0]
+                    dtok = ops.conv_fwd(dt0, _packed(wpe, dt, transpose=True))[0]
                     B, Cin, H, W = ctx.in_shape
                     g = ops.unpatchify(dtok, Cin, H, W, model.patch_size_val)
         ctx.save = None

@@ -114,12 +114,13 @@ def _side_stream(device):
 
 
 def _pack_all(model, dt, transpose):
-    packed = {}
-    for name in BLOCKS:
-        seq = getattr(model, name)
-        for ci in (0, 3):
-            packed[(name, ci)] = ops.PackedConv(seq[ci].weight, dt, transpose=transpose)
-    return packed
+    """All 3x3 weights of the network packed in one launch.  transpose: False (forward form), True
+    (data-gradient form) or "both" -> (forward dict, data-gradient dict)."""
+    keys = [(name, ci) for name in BLOCKS for ci in (0, 3)]
+    forms = (False, True) if transpose == "both" else (transpose,)
+    packs = ops.pack_many([(getattr(model, name)[ci].weight, tr) for tr in forms for name, ci in keys], dt)
+    dicts = [dict(zip(keys, packs[i * len(keys):(i + 1) * len(keys)])) for i in range(len(forms))]
+    return tuple(dicts) if transpose == "both" else dicts[0]
 
 
 class EvalEngine:
@@ -189,11 +190,8 @@ class _UNetTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, model, masks, *params):
         dt = model.compute_dtype
-        pk = _pack_all(model, dt, False)
-        # The data-gradient packs are queued now as well: the loss usually synchronises the host
-        # (its parts are Python floats), and 18 small launches right after that would run with the
-        # GPU idle in between.
-        ctx.pkT = _pack_all(model, dt, True)
+        # forward and data-gradient forms of all 18 weights: one launch
+        pk, ctx.pkT = _pack_all(model, dt, "both")
         saved = {}
         B = x.shape[0]
         h = ops.nchw_to_nhwc(x.detach(), dt)
