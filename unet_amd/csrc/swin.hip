@@ -356,6 +356,40 @@ __device__ __forceinline__ int region_of(int s, int extent) {
   return s < extent - WS ? 0 : (s < extent - WS / 2 ? 1 : 2);
 }
 
+// All-reduce over the 16 lanes of a DPP row (the lanes that share lane>>4) without touching LDS:
+// swap inside pairs, inside quads, mirror the 8-lane halves, mirror the row.  Every lane combines
+// the same pairs in the same tree, so all 16 end with the identical value.
+template <int CTRL> __device__ __forceinline__ float dpp_move(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_move<0xB1>(v));    // quad_perm [1,0,3,2]
+  v = fmaxf(v, dpp_move<0x4E>(v));    // quad_perm [2,3,0,1]
+  v = fmaxf(v, dpp_move<0x141>(v));   // row_half_mirror
+  v = fmaxf(v, dpp_move<0x140>(v));   // row_mirror
+  return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_move<0xB1>(v);
+  v += dpp_move<0x4E>(v);
+  v += dpp_move<0x141>(v);
+  v += dpp_move<0x140>(v);
+  return v;
+}
+
+// Four consecutive channels of one token from a C-layout accumulator register (rows = channels)
+template <typename T> __device__ __forceinline__ void store4(T* p, const f32x4& v, float scale = 1.0f) {
+  if constexpr (sizeof(T) == 2) {
+    typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+    u16x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = __builtin_bit_cast(unsigned short, from_f32<T>(v[r] * scale));
+    *reinterpret_cast<u16x4*>(p) = o;
+  } else {
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0] * scale, v[1] * scale, v[2] * scale, v[3] * scale};
+  }
+}
+
 // acc[mt][nt] += A(rows mt*16.., K) * B(rows nt*16.., K)^T with both operands row-major in LDS
 template <typename T, int MT, int NT, int CHUNKS>
 __device__ __forceinline__ void lds_gemm(const char* A, int lda, const char* Bm, int ldb, int lane,
@@ -401,17 +435,15 @@ __device__ __forceinline__ void window_softmax(f32x4 (&s)[4][4], const float* tb
         s[mt][nt][r] = v;
         mx = fmaxf(mx, v);
       }
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      mx = row16_max(mx);
       float sum = 0.f;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        const float e = expf(s[mt][nt][r] - mx);
+        const float e = __expf(s[mt][nt][r] - mx);
         s[mt][nt][r] = e;
         sum += e;
       }
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
+      sum = row16_sum(sum);
       const float inv = 1.0f / sum;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) s[mt][nt][r] *= inv;
@@ -484,20 +516,20 @@ __global__ __launch_bounds__(64) void window_attn_fwd_kernel(const T* __restrict
       for (int r = 0; r < 4; ++r)
         reinterpret_cast<T*>(Ps + (m * 16 + 4 * pg + r) * L::R64)[n * 16 + cl] = from_f32<T>(s[m][n][r]);
   __syncthreads();
-  f32x4 o[4][2];
+  // O^T[d][query] = sum_key V^T[d][key] P[query][key]: in the C layout a lane then holds four
+  // consecutive channels of one token, i.e. one 8-byte (bf16) store instead of four 2-byte ones
+  f32x4 o[2][4];
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+  for (int m = 0; m < 2; ++m)
 #pragma unroll
-    for (int n = 0; n < 2; ++n) o[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-  lds_gemm<T, 4, 2, L::C64>(Ps, L::R64, Vt, L::R64, lane, o);
+    for (int n = 0; n < 4; ++n) o[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  lds_gemm<T, 2, 4, L::C64>(Vt, L::R64, Ps, L::R64, lane, o);
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+  for (int n = 0; n < 4; ++n) {
+    const long tk = window_token(g, b, wy, wx, n * 16 + cl);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const long tk = window_token(g, b, wy, wx, m * 16 + 4 * pg + r);
-#pragma unroll
-      for (int n = 0; n < 2; ++n) out[tk * g.C + head * HD + n * 16 + cl] = from_f32<T>(o[m][n][r]);
-    }
+    for (int m = 0; m < 2; ++m) store4<T>(out + tk * g.C + head * HD + m * 16 + 4 * pg, o[m][n]);
+  }
 }
 
 // Backward of one (window, head): recomputes P, then dV = P^T dO, dP = dO V^T,
@@ -560,22 +592,19 @@ __global__ __launch_bounds__(64) void window_attn_bwd_kernel(const T* __restrict
       for (int r = 0; r < 4; ++r)
         reinterpret_cast<T*>(PA + (n * 16 + cl) * L::R64)[m * 16 + 4 * pg + r] = from_f32<T>(p[m][n][r]);
   __syncthreads();
-  {   // dV[key][d] = sum_query P^T[key][query] * dO^T[d][query]
-    f32x4 dv[4][2];
+  {   // dV^T[d][key] = sum_query dO^T[d][query] * P^T[key][query]  (a lane gets four channels of one token)
+    f32x4 dv[2][4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int n = 0; n < 2; ++n) dv[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    lds_gemm<T, 4, 2, L::C64>(PA, L::R64, Dt, L::R64, lane, dv);
+      for (int n = 0; n < 4; ++n) dv[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    lds_gemm<T, 2, 4, L::C64>(Dt, L::R64, PA, L::R64, lane, dv);
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int n = 0; n < 4; ++n) {
+      const long tk = window_token(g, b, wy, wx, n * 16 + cl);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const long tk = window_token(g, b, wy, wx, m * 16 + 4 * pg + r);
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-          dqkv[tk * 3 * g.C + 2 * g.C + head * HD + n * 16 + cl] = from_f32<T>(dv[m][n][r]);
-      }
+      for (int m = 0; m < 2; ++m) store4<T>(dqkv + tk * 3 * g.C + 2 * g.C + head * HD + m * 16 + 4 * pg, dv[m][n]);
+    }
   }
   // dP[query][key] = sum_d dO[query][d] * V[key][d]
   f32x4 dp[4][4];
@@ -591,8 +620,7 @@ __global__ __launch_bounds__(64) void window_attn_bwd_kernel(const T* __restrict
       float rs = 0.f;
 #pragma unroll
       for (int n = 0; n < 4; ++n) rs += dp[m][n][r] * p[m][n][r];
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) rs += __shfl_xor(rs, o, 64);
+      rs = row16_sum(rs);
 #pragma unroll
       for (int n = 0; n < 4; ++n) dp[m][n][r] = p[m][n][r] * (dp[m][n][r] - rs);   // dS
     }
@@ -609,41 +637,62 @@ __global__ __launch_bounds__(64) void window_attn_bwd_kernel(const T* __restrict
         reinterpret_cast<T*>(PB + j * L::R64)[i] = from_f32<T>(v);
       }
   __syncthreads();
-  {   // dQ[query][d] = scale * sum_key dS[query][key] * K^T[d][key];  dK[key][d] = scale * sum_query dS^T * Q^T
-    f32x4 dq[4][2], dk[4][2];
+  {   // dQ^T[d][query] = scale * sum_key K^T[d][key] * dS[query][key];  dK^T[d][key] = scale * sum_query Q^T * dS^T
+    f32x4 dq[2][4], dk[2][4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int n = 0; n < 2; ++n) dq[m][n] = dk[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    lds_gemm<T, 4, 2, L::C64>(PA, L::R64, Kt, L::R64, lane, dq);
-    lds_gemm<T, 4, 2, L::C64>(PB, L::R64, Qt, L::R64, lane, dk);
+      for (int n = 0; n < 4; ++n) dq[m][n] = dk[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    lds_gemm<T, 2, 4, L::C64>(Kt, L::R64, PA, L::R64, lane, dq);
+    lds_gemm<T, 2, 4, L::C64>(Qt, L::R64, PB, L::R64, lane, dk);
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int n = 0; n < 4; ++n) {
+      const long tk = window_token(g, b, wy, wx, n * 16 + cl);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const long tk = window_token(g, b, wy, wx, m * 16 + 4 * pg + r);
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-          dqkv[tk * 3 * g.C + head * HD + n * 16 + cl] = from_f32<T>(dq[m][n][r] * g.scale);
-          dqkv[tk * 3 * g.C + g.C + head * HD + n * 16 + cl] = from_f32<T>(dk[m][n][r] * g.scale);
-        }
-      }
-  }
-  // bias-table gradient of this (window, head): bin (dy,dx) sums dS[i][j] over yi-yj=dy, xi-xj=dx
-  // (dS as stored for the two products above, i.e. rounded to T)
-  for (int bin = lane; bin < 225; bin += 64) {
-    const int dy = bin / 15 - 7, dx = bin % 15 - 7;
-    float acc = 0.f;
-    for (int yj = 0; yj < WS; ++yj) {
-      const int yi = yj + dy;
-      if (yi < 0 || yi >= WS) continue;
-      for (int xj = 0; xj < WS; ++xj) {
-        const int xi = xj + dx;
-        if (xi < 0 || xi >= WS) continue;
-        acc += to_f32(reinterpret_cast<const T*>(PA + (yi * WS + xi) * L::R64)[yj * WS + xj]);
+      for (int m = 0; m < 2; ++m) {
+        store4<T>(dqkv + tk * 3 * g.C + head * HD + m * 16 + 4 * pg, dq[m][n], g.scale);
+        store4<T>(dqkv + tk * 3 * g.C + g.C + head * HD + m * 16 + 4 * pg, dk[m][n], g.scale);
       }
     }
-    dtable_partials[(long)blockIdx.x * 225 + bin] = acc;
+  }
+  // Bias-table gradient of this (window, head): bin (dy,dx) sums dS[i][j] (as stored for the two
+  // products above, i.e. rounded to T) over yi-yj = dy, xi-xj = dx.  Two steps, fixed order:
+  // lane (yi,yj) reads its 8x8 block of dS (rows 8yi.., columns 8yj..: 16-byte reads) and sums the
+  // block's 15 diagonals in registers; then each bin adds the up to eight blocks with yi-yj = dy.
+  {
+    constexpr int E = Vec16<T>::N;
+    const int yi = lane >> 3, yj = lane & 7;
+    float diag[2 * WS - 1];
+#pragma unroll
+    for (int k = 0; k < 2 * WS - 1; ++k) diag[k] = 0.f;
+#pragma unroll
+    for (int xi = 0; xi < WS; ++xi) {
+      const T* rowp = reinterpret_cast<const T*>(PA + (yi * WS + xi) * L::R64) + yj * WS;
+#pragma unroll
+      for (int part = 0; part < WS / E; ++part) {
+        const Vec16<T> v = load16(rowp + part * E);
+#pragma unroll
+        for (int e = 0; e < E; ++e) diag[xi - (part * E + e) + WS - 1] += to_f32(v.v[e]);
+      }
+    }
+    __syncthreads();                 // everyone has read dS: the dS^T tile is free to hold the block sums
+    float* blk = reinterpret_cast<float*>(PB);                 // [yi][yj][16]
+    static_assert(NTOK * 16 * 4 <= NTOK * L::R64, "block sums fit the dS^T tile");
+#pragma unroll
+    for (int k = 0; k < 2 * WS - 1; ++k) blk[lane * 16 + k] = diag[k];
+    __syncthreads();
+    for (int bin = lane; bin < 225; bin += 64) {
+      const int dy = bin / 15 - 7, dxk = bin % 15;
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < WS; ++j) {
+        const int i = j + dy;
+        const bool ok = i >= 0 && i < WS;
+        const float v = blk[((ok ? i : 0) * WS + j) * 16 + dxk];
+        acc += ok ? v : 0.f;
+      }
+      dtable_partials[(long)blockIdx.x * 225 + bin] = acc;
+    }
   }
 }
 
