@@ -369,6 +369,50 @@ __global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restric
   }
 }
 
+// BatchNorm backward, everything between the reduction and the apply pass in ONE launch: sums the
+// [nparts][2][C] partials (double, fixed order) into sums[0:C] = sum dz and sums[C:2C] = sum dz*xhat,
+// writes (or accumulates into) dbeta / dgamma, and derives the apply pass's coefficients (see
+// bn_bwd_coef_kernel) from the rounded sums exactly as the separate kernels do.
+__global__ __launch_bounds__(256) void bn_bwd_sums_coef_kernel(const float* __restrict__ partials, int nparts, int C,
+                                                               float* __restrict__ sums, float* dbeta, float* dgamma,
+                                                               int accumulate, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd, float inv_n,
+                                                               float* __restrict__ coef) {
+  __shared__ double red[2][64][4];
+  const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;
+  const int c = blockIdx.x * 4 + cl;
+  double s = 0.0, q = 0.0;
+  if (c < C)
+    for (int r = rl; r < nparts; r += 64) {
+      s += (double)partials[((long)r * 2) * C + c];
+      q += (double)partials[((long)r * 2 + 1) * C + c];
+    }
+  red[0][rl][cl] = s;
+  red[1][rl][cl] = q;
+  __syncthreads();
+  if (threadIdx.x < 4 && blockIdx.x * 4 + threadIdx.x < C) {
+    const int cc = blockIdx.x * 4 + threadIdx.x;
+    double ss = 0.0, qq = 0.0;
+    for (int r = 0; r < 64; ++r) {
+      ss += red[0][r][threadIdx.x];
+      qq += red[1][r][threadIdx.x];
+    }
+    const float sdz = (float)ss, sdzx = (float)qq;
+    sums[cc] = sdz;
+    sums[C + cc] = sdzx;
+    if (dbeta) dbeta[cc] = accumulate ? dbeta[cc] + sdz : sdz;
+    if (dgamma) dgamma[cc] = accumulate ? dgamma[cc] + sdzx : sdzx;
+    const float sc = scale[cc];
+    const float k1 = -sc * sdzx * invstd[cc] * inv_n;
+    coef[cc] = sc;
+    coef[C + cc] = shift[cc];
+    coef[2 * C + cc] = k1;
+    coef[3 * C + cc] = -sc * sdz * inv_n - k1 * mean[cc];
+  }
+}
+
 // Per-channel coefficients of the BatchNorm backward: with dz = keep * g * [z > 0],
 //   dy = scale * (dz - sum_dz/n - xhat * sum_dzxhat/n) = scale*dz + k1*y + k0,
 //   k1 = -scale * sum_dzxhat * invstd / n,   k0 = -scale * sum_dz / n - k1 * mean.
@@ -843,19 +887,11 @@ int unetk_bn_act_bwd(const void* g, const void* y, void* dy, int B, int H, int W
   DISPATCH_T(dtype, hipLaunchKernelGGL((channel_reduce_kernel<T, 0>), dim3(nblk), dim3(RED_THREADS), 0,
                                        stream, r));
   UNETK_CHECK_LAUNCH();
-  // sums[0:C] = sum dz (= dbeta), sums[C:2C] = sum dz*xhat (= dgamma)
-  hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, partials, nblk, C, C, sums,
-                     sums + C, 0);
-  UNETK_CHECK_LAUNCH();
-  if (dbeta || dgamma) {
-    hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, partials, nblk, C, C, dbeta,
-                       dgamma, accumulate);
-    UNETK_CHECK_LAUNCH();
-  }
-  // coefficients live behind the two sum rows: sums must hold 6*C floats
+  // sums[0:C] = sum dz (= dbeta), sums[C:2C] = sum dz*xhat (= dgamma); the coefficients live behind
+  // the two sum rows: sums must hold 6*C floats
   float* coef = sums + 2 * C;
-  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, scale, shift, mean, invstd,
-                     sums, 1.0f / (float)npix, coef, C);
+  hipLaunchKernelGGL(bn_bwd_sums_coef_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, partials, nblk, C, sums, dbeta,
+                     dgamma, accumulate, scale, shift, mean, invstd, 1.0f / (float)npix, coef);
   UNETK_CHECK_LAUNCH();
   {
     const int lanes = RED_THREADS / (C / E);
