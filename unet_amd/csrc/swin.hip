@@ -22,6 +22,27 @@ __device__ __forceinline__ float gelu_grad(float x) {
   return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
 }
 
+// All-reduce over the 16 lanes of a DPP row (the lanes that share lane>>4) without touching LDS:
+// swap inside pairs, inside quads, mirror the 8-lane halves, mirror the row.  Every lane combines
+// the same pairs in the same tree, so all 16 end with the identical value.
+template <int CTRL> __device__ __forceinline__ float dpp_move(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_move<0xB1>(v));    // quad_perm [1,0,3,2]
+  v = fmaxf(v, dpp_move<0x4E>(v));    // quad_perm [2,3,0,1]
+  v = fmaxf(v, dpp_move<0x141>(v));   // row_half_mirror
+  v = fmaxf(v, dpp_move<0x140>(v));   // row_mirror
+  return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_move<0xB1>(v);
+  v += dpp_move<0x4E>(v);
+  v += dpp_move<0x141>(v);
+  v += dpp_move<0x140>(v);
+  return v;
+}
+
 // ------------------------------------------------------------------ LayerNorm over channels
 // One wavefront per token.
 template <typename T>
@@ -104,6 +125,172 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
       o.v[e] = from_f32<T>(rs * (g - s1 - xh * s2) + (add ? to_f32(av.v[e]) : 0.f));
     }
     store16(dx + tok * C + c, o);
+  }
+}
+
+// ---- LayerNorm with a group of G lanes per token (G = 16, 32 or 64: the smallest that holds the
+// token's 16-byte vectors in at most LN_MAXV per lane).  A 96-channel bf16 token is 12 vectors: one
+// wave takes four tokens instead of one, every vector is read once and kept in registers, and the
+// group reductions stay inside a DPP row for G = 16.
+constexpr int LN_MAXV = 6;
+
+template <int G> __device__ __forceinline__ float group_sum(float v) {
+  v = row16_sum(v);
+  if (G >= 32) v += __shfl_xor(v, 16, 64);
+  if (G >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+template <typename T, int G>
+__global__ __launch_bounds__(256) void layernorm_fwd_group_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta,
+                                                                  float* __restrict__ mean_out,
+                                                                  float* __restrict__ rstd_out, long ntok, int C,
+                                                                  float eps) {
+  constexpr int E = Vec16<T>::N;
+  const int CG = C / E;
+  const int gl = threadIdx.x % G;
+  const long tok = (long)blockIdx.x * (256 / G) + threadIdx.x / G;
+  const bool live = tok < ntok;                      // (dead groups still take part in the shuffles)
+  const T* xr = x + (live ? tok : 0) * C;
+  Vec16<T> v[LN_MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) {
+    const int cg = k * G + gl;
+    if (cg < CG) {
+      v[k] = load16(xr + cg * E);
+#pragma unroll
+      for (int e = 0; e < E; ++e) s += to_f32(v[k].v[e]);
+    }
+  }
+  const float mean = group_sum<G>(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k)
+    if (k * G + gl < CG) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const float d = to_f32(v[k].v[e]) - mean;
+        q += d * d;
+      }
+    }
+  const float rstd = 1.0f / sqrtf(group_sum<G>(q) / (float)C + eps);
+  if (!live) return;
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) {
+    const int cg = k * G + gl;
+    if (cg < CG) {
+      Vec16<T> o;
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        o.v[e] = from_f32<T>((to_f32(v[k].v[e]) - mean) * rstd * gamma[cg * E + e] + beta[cg * E + e]);
+      store16(y + tok * C + cg * E, o);
+    }
+  }
+  if (gl == 0) {
+    mean_out[tok] = mean;
+    rstd_out[tok] = rstd;
+  }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g*xhat)) + add, g = dy * gamma; and, in the same pass, this
+// workgroup's share of dgamma = sum dy*xhat and dbeta = sum dy: workgroup b walks tokens
+// [b*chunk, (b+1)*chunk), each lane keeps the sums of its channel vectors in registers, the token
+// groups of the workgroup are added through LDS in a fixed order -> partials[b][2][C].
+template <typename T, int G>
+__global__ __launch_bounds__(256) void layernorm_bwd_group_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ mean,
+                                                                  const float* __restrict__ rstd,
+                                                                  const T* __restrict__ add, T* __restrict__ dx,
+                                                                  long ntok, int C, int chunk,
+                                                                  float* __restrict__ partials) {
+  constexpr int E = Vec16<T>::N;
+  constexpr int TPW = 256 / G;
+  __shared__ float red[2][256 * E];
+  const int CG = C / E;
+  const int gl = threadIdx.x % G, tg = threadIdx.x / G;
+  const long pbeg = (long)blockIdx.x * chunk;
+  long pend = pbeg + chunk;
+  if (pend > ntok) pend = ntok;
+  float ag[LN_MAXV][E], ab[LN_MAXV][E];
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k)
+#pragma unroll
+    for (int e = 0; e < E; ++e) ag[k][e] = ab[k][e] = 0.f;
+  for (long t0 = pbeg; t0 < pend; t0 += TPW) {        // (uniform trip count: the shuffles need whole waves)
+    const long tok = t0 + tg;
+    const bool live = tok < pend;
+    const long tk = live ? tok : pbeg;
+    const float mu = mean[tk], rs = rstd[tk];
+    Vec16<T> dv[LN_MAXV], xv[LN_MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+      const int cg = k * G + gl;
+      if (cg < CG) {
+        dv[k] = load16(dy + tk * C + cg * E);
+        xv[k] = load16(x + tk * C + cg * E);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const float d = live ? to_f32(dv[k].v[e]) : 0.f;
+          const float xh = (to_f32(xv[k].v[e]) - mu) * rs;
+          const float g = d * gamma[cg * E + e];
+          s1 += g;
+          s2 += g * xh;
+          ag[k][e] += d * xh;
+          ab[k][e] += d;
+        }
+      }
+    }
+    s1 = group_sum<G>(s1) / (float)C;
+    s2 = group_sum<G>(s2) / (float)C;
+    if (live) {
+#pragma unroll
+      for (int k = 0; k < LN_MAXV; ++k) {
+        const int cg = k * G + gl;
+        if (cg < CG) {
+          Vec16<T> av = zero16<T>();
+          if (add != nullptr) av = load16(add + tok * C + cg * E);
+          Vec16<T> o;
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            const float g = to_f32(dv[k].v[e]) * gamma[cg * E + e];
+            const float xh = (to_f32(xv[k].v[e]) - mu) * rs;
+            o.v[e] = from_f32<T>(rs * (g - s1 - xh * s2) + (add ? to_f32(av.v[e]) : 0.f));
+          }
+          store16(dx + tok * C + cg * E, o);
+        }
+      }
+    }
+  }
+  if (partials == nullptr) return;
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) {
+    if (k * G >= CG) break;                             // (uniform)
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      red[0][threadIdx.x * E + e] = ag[k][e];
+      red[1][threadIdx.x * E + e] = ab[k][e];
+    }
+    __syncthreads();
+    // G*E channels of this vector slot, TPW token groups each
+    for (int i = threadIdx.x; i < G * E; i += 256) {
+      const int l = i / E, e = i - l * E;
+      const int c = (k * G + l) * E + e;
+      if (c < C) {
+        float t0 = 0.f, t1 = 0.f;
+        for (int g2 = 0; g2 < TPW; ++g2) {
+          t0 += red[0][(g2 * G + l) * E + e];
+          t1 += red[1][(g2 * G + l) * E + e];
+        }
+        partials[((long)blockIdx.x * 2) * C + c] = t0;
+        partials[((long)blockIdx.x * 2 + 1) * C + c] = t1;
+      }
+    }
   }
 }
 
@@ -354,27 +541,6 @@ struct AttnGeom {
 
 __device__ __forceinline__ int region_of(int s, int extent) {
   return s < extent - WS ? 0 : (s < extent - WS / 2 ? 1 : 2);
-}
-
-// All-reduce over the 16 lanes of a DPP row (the lanes that share lane>>4) without touching LDS:
-// swap inside pairs, inside quads, mirror the 8-lane halves, mirror the row.  Every lane combines
-// the same pairs in the same tree, so all 16 end with the identical value.
-template <int CTRL> __device__ __forceinline__ float dpp_move(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float row16_max(float v) {
-  v = fmaxf(v, dpp_move<0xB1>(v));    // quad_perm [1,0,3,2]
-  v = fmaxf(v, dpp_move<0x4E>(v));    // quad_perm [2,3,0,1]
-  v = fmaxf(v, dpp_move<0x141>(v));   // row_half_mirror
-  v = fmaxf(v, dpp_move<0x140>(v));   // row_mirror
-  return v;
-}
-__device__ __forceinline__ float row16_sum(float v) {
-  v += dpp_move<0xB1>(v);
-  v += dpp_move<0x4E>(v);
-  v += dpp_move<0x141>(v);
-  v += dpp_move<0x140>(v);
-  return v;
 }
 
 // Four consecutive channels of one token from a C-layout accumulator register (rows = channels)
@@ -713,6 +879,13 @@ inline int slab_channels(int C, int E) {
   return C / n;
 }
 
+// lanes per token for the grouped LayerNorm kernels (0: too many vectors per token for them)
+inline int ln_group(int cg) {
+  for (int g = 16; g <= 64; g *= 2)
+    if (cg <= g * (g < 64 ? 1 : LN_MAXV)) return g;
+  return 0;
+}
+
 inline int tok_blocks(long ntok) {
   long n = (ntok + 63) / 64;
   if (n > 1024) n = 1024;
@@ -743,8 +916,17 @@ int unetk_layernorm_fwd(const void* x, void* y, const float* gamma, const float*
   UNETK_CHECK_ARG(x && y && gamma && beta && mean && rstd && ntok > 0, "layernorm_fwd: bad arguments");
   CHECK_DT("layernorm_fwd", dtype);
   UNETK_CHECK_ARG(C % VEC_OF(dtype) == 0, "layernorm_fwd: C=%d not a multiple of %d", C, VEC_OF(dtype));
-  DISPATCH_T(dtype, hipLaunchKernelGGL(layernorm_fwd_kernel<T>, dim3(cdiv(ntok, 4)), dim3(256), 0, stream,
-                                       (const T*)x, (T*)y, gamma, beta, mean, rstd, (long)ntok, C, eps));
+  const int G = ln_group(C / VEC_OF(dtype));
+#define LN_FWD(G_)                                                                                              \
+  DISPATCH_T(dtype, hipLaunchKernelGGL((layernorm_fwd_group_kernel<T, G_>), dim3(cdiv(ntok, 256 / G_)), dim3(256), 0, \
+                                       stream, (const T*)x, (T*)y, gamma, beta, mean, rstd, (long)ntok, C, eps))
+  if (G == 16) LN_FWD(16);
+  else if (G == 32) LN_FWD(32);
+  else if (G == 64) LN_FWD(64);
+  else   // more vectors per token than the grouped kernel keeps in registers: one wave per token
+    DISPATCH_T(dtype, hipLaunchKernelGGL(layernorm_fwd_kernel<T>, dim3(cdiv(ntok, 4)), dim3(256), 0, stream,
+                                         (const T*)x, (T*)y, gamma, beta, mean, rstd, (long)ntok, C, eps));
+#undef LN_FWD
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }
@@ -758,13 +940,33 @@ int unetk_layernorm_bwd(const void* dy, const void* x, const float* gamma, const
   UNETK_CHECK_ARG(dy && x && gamma && mean && rstd && dx && partials && ntok > 0, "layernorm_bwd: bad arguments");
   CHECK_DT("layernorm_bwd", dtype);
   UNETK_CHECK_ARG(C % VEC_OF(dtype) == 0, "layernorm_bwd: unsupported C=%d", C);
+  const int G = ln_group(C / VEC_OF(dtype));
+  const int nb = tok_blocks(ntok);
+  const int chunk = cdiv(ntok, nb);
+  const bool want_sums = dgamma || dbeta;
+  if (G != 0) {
+    // dx and the workgroups' dgamma / dbeta partials in one pass over dy and x
+#define LN_BWD(G_)                                                                                             \
+  DISPATCH_T(dtype, hipLaunchKernelGGL((layernorm_bwd_group_kernel<T, G_>), dim3(cdiv(ntok, chunk)), dim3(256), 0,   \
+                                       stream, (const T*)dy, (const T*)x, gamma, mean, rstd, (const T*)add, (T*)dx,  \
+                                       (long)ntok, C, chunk, want_sums ? partials : nullptr))
+    if (G == 16) LN_BWD(16);
+    else if (G == 32) LN_BWD(32);
+    else LN_BWD(64);
+#undef LN_BWD
+    UNETK_CHECK_LAUNCH();
+    if (want_sums) {
+      hipLaunchKernelGGL(partial_sum2_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, partials, cdiv(ntok, chunk), C,
+                         dgamma, dbeta);
+      UNETK_CHECK_LAUNCH();
+    }
+    return UNETK_OK;
+  }
   DISPATCH_T(dtype, hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3(cdiv(ntok, 4)), dim3(256), 0, stream,
                                        (const T*)dy, (const T*)x, gamma, mean, rstd, (const T*)add, (T*)dx,
                                        (long)ntok, C));
   UNETK_CHECK_LAUNCH();
-  if (dgamma || dbeta) {
-    const int nb = tok_blocks(ntok);
-    const int chunk = cdiv(ntok, nb);
+  if (want_sums) {
     const int CS = slab_channels(C, VEC_OF(dtype));
     DISPATCH_T(dtype, hipLaunchKernelGGL((token_reduce_kernel<T, 1>), dim3(nb, C / CS), dim3(256), 0, stream,
                                          (const T*)dy, C, (const T*)x, mean, rstd, (long)ntok, C, CS, chunk,
