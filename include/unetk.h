@@ -82,6 +82,14 @@ int64_t unetk_conv_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Co, in
 int unetk_conv_wgrad(const void* in, int ldin, const void* dy, int lddy, float* dw, int B, int H, int W,
                      int Ci, int Co, int ks, int dtype, void* workspace, int64_t workspace_bytes,
                      int accumulate, unetk_stream_t stream);
+/* nn.Linear backward over tokens (swin_unet_model.py:234,236,298,301 through autograd): weight
+ * gradient dw[Co][Ci] as the 1x1 case above AND the bias gradient dbias[Co] = sum over tokens of
+ * dy, from the same pass over dy (the dy fragments the MFMAs load are multiplied by a matrix of
+ * ones as well).  bfloat16 only.  Workspace: unetk_linear_wgrad_workspace_bytes. */
+int64_t unetk_linear_wgrad_workspace_bytes(int64_t ntok, int Ci, int Co, int dtype);
+int unetk_linear_wgrad(const void* in, int ldin, const void* dy, int lddy, float* dw, float* dbias, int64_t ntok,
+                       int Ci, int Co, int dtype, void* workspace, int64_t workspace_bytes, int accumulate,
+                       unetk_stream_t stream);
 
 /* ---- layout ------------------------------------------------------------------------ */
 int unetk_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int ld, int dtype,

@@ -250,3 +250,22 @@ def test_conv_fused_pool_and_head(dt, shape):
         assert o is None and p is None
         want = ops.head1x1_fwd(y, hw, hb)
         assert rel(head.cpu(), want.cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("ntok,Ci,Co", [(64 * 64 * 4, 96, 288), (4096, 384, 96), (1000, 192, 192), (8 * 8 * 3, 768, 3072),
+                                        (256, 32, 48)])
+def test_linear_wgrad_with_bias(ntok, Ci, Co):
+    """nn.Linear backward over tokens: dw = dy^T x and db = sum dy from one pass (bf16), against fp64 sums of the
+    same bf16-rounded operands."""
+    from unet_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(ntok + Ci)
+    x = torch.randn((ntok, Ci), device="cuda", generator=g).to(torch.bfloat16)
+    dy = torch.randn((ntok, Co), device="cuda", generator=g).to(torch.bfloat16)
+    dw, db = ops.linear_wgrad(x, dy, Ci, Co)
+    want_w = dy.double().t() @ x.double()
+    want_b = dy.double().sum(0)
+    assert dw.shape == (Co, Ci) and db.shape == (Co,)
+    assert float((dw.double() - want_w).norm() / want_w.norm()) < 1e-5
+    assert float((db.double() - want_b).norm() / want_b.norm()) < 1e-5
+    dw2, db2 = ops.linear_wgrad(x, dy, Ci, Co)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)          # fixed summation order

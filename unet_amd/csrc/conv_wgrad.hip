@@ -33,6 +33,7 @@ struct WgradArgs {
   const void* in;
   const void* dy;
   float* slab;
+  float* bias_slab;         // [nsplit][Co_pad] column sums of dy (1x1 bf16 only), or null
   int ldin, lddy;
   int B, H, W, Ci, Co;
   int Ci_pad, Co_pad;
@@ -95,6 +96,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
   constexpr int KCI = NWN * NSL * 16;           // input channels per workgroup
   constexpr int TAPS = KS * KS;
   constexpr int NACC = TAPS * NSL;              // accumulator tiles per 16 output channels
+  // 1x1 bf16 (linear layers): one more tile per row block can take sum_pixels dy (the bias gradient),
+  // as dy^T times a matrix of ones, from the fragments the weight gradient loads anyway
+  constexpr int NB = (BF && KS == 1) ? 1 : 0;
   constexpr int HW_ = (KS == 3) ? TW + 2 : TW;  // halo width
   constexpr int HH_ = (KS == 3) ? TR + 2 : TR;
   constexpr int HPIX = HH_ * HW_;
@@ -137,11 +141,12 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
   const T* dy = reinterpret_cast<const T*>(a.dy);
   const T* zero = reinterpret_cast<const T*>(wgrad_zero_page);
 
-  f32x4 acc[MT][NACC];
+  f32x4 acc[MT][NACC + NB];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int t = 0; t < NACC; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NACC + NB; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool want_bias = NB > 0 && a.bias_slab != nullptr;
 
   const int g = lane >> 4, li = lane & 15, q = li >> 2, p4 = li & 3;
 
@@ -279,6 +284,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
           for (int kx = 0; kx < KS; ++kx)
             acc[m][(ky * KS + kx) * NSL + sl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                 af[m], __builtin_bit_cast(bf16x8, win[kx]), acc[m][(ky * KS + kx) * NSL + sl], 0, 0, 0);
+          if constexpr (NB > 0 && u % SUB == 0) {
+            if (want_bias) {      // (uniform) every column of the tile = sum over the k-step's pixels
+              const u32x4 ones = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+              acc[m][NACC] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], __builtin_bit_cast(bf16x8, ones),
+                                                                     acc[m][NACC], 0, 0, 0);
+            }
+          }
           if constexpr (reload) load_a(st + 1, m);
         }
         // issue order: first MFMA, window reads, rest of the row block, its reload, next row block ...
@@ -366,7 +378,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
 
   // Sum the k-residues of the workgroup through LDS (fixed order: residue w + half into w, halving),
   // one 16-channel row block at a time so the exchange area is 4 waves x 9 KiB at most.
-  static_assert(4 * NACC * 4 * 64 * 4 <= STAGE, "exchange area");
+  constexpr int NACCX = NACC + NB;
+  static_assert(4 * NACCX * 4 * 64 * 4 <= STAGE, "exchange area");
   static_assert(BF || NSL == 1, "channel slices per wave: bf16 only");
   float* xch = reinterpret_cast<float*>(buf0);
 #pragma unroll
@@ -375,17 +388,17 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
     for (int half = NWK / 2; half >= 1; half >>= 1) {
       __syncthreads();   // (first trip: every wave is done with the last tile)
       if (wk >= half && wk < 2 * half) {
-        float* dst = xch + ((wk - half) * NWN + wn) * (NACC * 4 * 64) + lane;
+        float* dst = xch + ((wk - half) * NWN + wn) * (NACCX * 4 * 64) + lane;
 #pragma unroll
-        for (int t = 0; t < NACC; ++t)
+        for (int t = 0; t < NACCX; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) dst[(t * 4 + r) * 64] = acc[m][t][r];
       }
       __syncthreads();
       if (wk < half) {
-        const float* src = xch + (wk * NWN + wn) * (NACC * 4 * 64) + lane;
+        const float* src = xch + (wk * NWN + wn) * (NACCX * 4 * 64) + lane;
 #pragma unroll
-        for (int t = 0; t < NACC; ++t)
+        for (int t = 0; t < NACCX; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[m][t][r] += src[(t * 4 + r) * 64];
       }
@@ -407,6 +420,25 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
           const int ci = ci0 + (wn * NSL + sl) * 16 + li;
           slab[((long)co * TAPS + t) * a.Ci_pad + ci] = acc[m][t * NSL + sl][r];
         }
+  if constexpr (NB > 0) {
+    // the workgroups of the first input-channel chunk also hand over the column sums of dy
+    if (want_bias && ci0 == 0 && wn == 0 && li == 0) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a.bias_slab[(long)bz * a.Co_pad + co0 + m * 16 + 4 * g + r] = acc[m][NACC][r];
+    }
+  }
+}
+
+// db[co] (+)= sum_s bias_slab[s][co], slabs in a fixed order
+__global__ void wgrad_bias_reduce_kernel(const float* __restrict__ bias_slab, float* __restrict__ db, int nslab,
+                                         int Co, int Co_pad, int accumulate) {
+  const int co = blockIdx.x * blockDim.x + threadIdx.x;
+  if (co >= Co) return;
+  float s = 0.f;
+  for (int i = 0; i < nslab; ++i) s += bias_slab[(long)i * Co_pad + co];
+  db[co] = accumulate ? db[co] + s : s;
 }
 
 // dw[co][ci][tap] (+)= sum_s slab[s][co][tap][ci].  One workgroup per (co, tap, 32-channel chunk):
@@ -531,9 +563,9 @@ int64_t unetk_conv_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Co, in
   return (int64_t)p.nsplit * p.Co_pad * ks * ks * p.Ci_pad * 4;
 }
 
-int unetk_conv_wgrad(const void* in, int ldin, const void* dy, int lddy, float* dw, int B, int H, int W,
-                     int Ci, int Co, int ks, int dtype, void* workspace, int64_t workspace_bytes,
-                     int accumulate, hipStream_t stream) {
+static int wgrad_impl(const void* in, int ldin, const void* dy, int lddy, float* dw, float* dbias, int B, int H, int W,
+                      int Ci, int Co, int ks, int dtype, void* workspace, int64_t workspace_bytes,
+                      int accumulate, hipStream_t stream) {
   UNETK_CHECK_ARG(in && dy && dw && workspace, "conv_wgrad: null pointer");
   UNETK_CHECK_ARG(ks == 1 || ks == 3, "conv_wgrad: kernel size %d (1 or 3)", ks);
   UNETK_CHECK_ARG(dtype == UNETK_F32 || dtype == UNETK_BF16, "conv_wgrad: bad dtype %d", dtype);
@@ -545,11 +577,12 @@ int unetk_conv_wgrad(const void* in, int ldin, const void* dy, int lddy, float* 
                   "conv_wgrad: tensors of 2^31 elements or more are not supported");
   refold_1x1(B, H, W, ks);
   const WgradPlan p = plan_wgrad(B, H, W, Ci, Co, dtype, ks);
-  const int64_t need = unetk_conv_wgrad_workspace_bytes(B, H, W, Ci, Co, ks, dtype);
+  const int64_t main_bytes = (int64_t)p.nsplit * p.Co_pad * ks * ks * p.Ci_pad * 4;
+  const int64_t need = main_bytes + (dbias ? (int64_t)p.nsplit * p.Co_pad * 4 : 0);
   UNETK_CHECK_ARG(workspace_bytes >= need, "conv_wgrad: workspace %lld < %lld bytes",
                   (long long)workspace_bytes, (long long)need);
   WgradArgs a;
-  a.in = in; a.dy = dy; a.slab = (float*)workspace; a.ldin = ldin; a.lddy = lddy;
+  a.in = in; a.dy = dy; a.slab = (float*)workspace; a.bias_slab = dbias ? (float*)((char*)workspace + main_bytes) : nullptr; a.ldin = ldin; a.lddy = lddy;
   a.B = B; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.Ci_pad = p.Ci_pad; a.Co_pad = p.Co_pad;
   a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.ntiles = p.ntiles; a.nsplit = p.nsplit;
   a.gx = p.Ci_pad / (p.nwn == 1 ? 64 : p.nwn * 16); a.gy = p.Co_pad / (p.mt * 16);
@@ -563,7 +596,37 @@ int unetk_conv_wgrad(const void* in, int ldin, const void* dy, int lddy, float* 
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)nblocks), dim3(256), 0, stream, a.slab, dw,
                      p.nsplit, Co, Ci, p.Co_pad, p.Ci_pad, ks * ks, accumulate);
   UNETK_CHECK_LAUNCH();
+  if (dbias) {
+    hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3(cdiv(Co, 256)), dim3(256), 0, stream, a.bias_slab, dbias,
+                       p.nsplit, Co, p.Co_pad, accumulate);
+    UNETK_CHECK_LAUNCH();
+  }
   return UNETK_OK;
+}
+
+int unetk_conv_wgrad(const void* in, int ldin, const void* dy, int lddy, float* dw, int B, int H, int W,
+                     int Ci, int Co, int ks, int dtype, void* workspace, int64_t workspace_bytes,
+                     int accumulate, hipStream_t stream) {
+  return wgrad_impl(in, ldin, dy, lddy, dw, nullptr, B, H, W, Ci, Co, ks, dtype, workspace, workspace_bytes,
+                    accumulate, stream);
+}
+
+int64_t unetk_linear_wgrad_workspace_bytes(int64_t npix, int Ci, int Co, int dtype) {
+  int B = 1, H = 1, W = (int)npix;
+  if (npix >= (1LL << 31)) return -1;
+  refold_1x1(B, H, W, 1);
+  const WgradPlan p = plan_wgrad(B, H, W, Ci, Co, dtype, 1);
+  return (int64_t)p.nsplit * p.Co_pad * p.Ci_pad * 4 + (int64_t)p.nsplit * p.Co_pad * 4;
+}
+
+int unetk_linear_wgrad(const void* in, int ldin, const void* dy, int lddy, float* dw, float* dbias, int64_t npix,
+                       int Ci, int Co, int dtype, void* workspace, int64_t workspace_bytes, int accumulate,
+                       hipStream_t stream) {
+  UNETK_CHECK_ARG(dbias != nullptr, "linear_wgrad: null bias gradient (use conv_wgrad)");
+  UNETK_CHECK_ARG(dtype == UNETK_BF16, "linear_wgrad: bfloat16 only (the bias sums ride on the bf16 MFMA path)");
+  UNETK_CHECK_ARG(npix > 0 && npix < (1LL << 31), "linear_wgrad: bad token count");
+  return wgrad_impl(in, ldin, dy, lddy, dw, dbias, 1, 1, (int)npix, Ci, Co, 1, dtype, workspace, workspace_bytes,
+                    accumulate, stream);
 }
 
 }  // extern "C"

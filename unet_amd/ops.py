@@ -190,6 +190,22 @@ def conv_fwd(x: torch.Tensor, pw: PackedConv, Ci: Optional[int] = None, Co: Opti
     return out, stats
 
 
+def linear_wgrad(x: torch.Tensor, dy: torch.Tensor, Ci: int, Co: int):
+    """(dw (Co,Ci), db (Co,)) fp32 of a linear layer over tokens: x (..., ldx) and dy (..., lddy) channels-last.
+    bfloat16 with unpadded channel counts: one pass over dy gives both; otherwise conv_wgrad + channel_sum."""
+    dt = x.dtype
+    if dt != torch.bfloat16 or pad_channels(Ci, dt) != Ci or pad_channels(Co, dt) != Co:
+        return conv_wgrad(x, dy, Ci, Co, 1).view(Co, Ci), channel_sum(dy, Co)
+    ntok = x.numel() // x.shape[-1]
+    need = _lib.load().unetk_linear_wgrad_workspace_bytes(ntok, Ci, Co, dtype_code(dt))
+    workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
+    dw = torch.empty((Co, Ci), dtype=torch.float32, device=x.device)
+    db = torch.empty((Co,), dtype=torch.float32, device=x.device)
+    call("unetk_linear_wgrad", ptr(x), x.stride(-2), ptr(dy), dy.stride(-2), ptr(dw), ptr(db), ntok, Ci, Co,
+         dtype_code(dt), ptr(workspace), need, 0, stream())
+    return dw, db
+
+
 def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, Ci: int, Co: int, ks: int,
                dw: Optional[torch.Tensor] = None, accumulate: bool = False,
                workspace: Optional[torch.Tensor] = None) -> torch.Tensor:

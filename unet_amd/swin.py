@@ -237,9 +237,11 @@ def _linear(x, w, b, dt, act=0, resid=None, keep=None, out=None):
 
 def _linear_bwd(x, dy, w, dt, grads, wname, bname, need_dx=True):
     Co, Ci = w.shape[0], w.shape[1]
-    grads[wname] = ops.conv_wgrad(x, dy, Ci, Co, 1).view(w.shape)
     if bname is not None:
-        grads[bname] = ops.channel_sum(dy, Co)
+        dw, grads[bname] = ops.linear_wgrad(x, dy, Ci, Co)
+        grads[wname] = dw.view(w.shape)
+    else:
+        grads[wname] = ops.conv_wgrad(x, dy, Ci, Co, 1).view(w.shape)
     if need_dx:
         return ops.conv_fwd(dy, _packed(w.view(Co, Ci), dt, transpose=True))[0]
     return None
