@@ -431,23 +431,25 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
   }
 }
 
-// db[co] (+)= sum_s bias_slab[s][co], slabs in a fixed order
-__global__ void wgrad_bias_reduce_kernel(const float* __restrict__ bias_slab, float* __restrict__ db, int nslab,
-                                         int Co, int Co_pad, int accumulate) {
-  const int co = blockIdx.x * blockDim.x + threadIdx.x;
-  if (co >= Co) return;
-  float s = 0.f;
-  for (int i = 0; i < nslab; ++i) s += bias_slab[(long)i * Co_pad + co];
-  db[co] = accumulate ? db[co] + s : s;
-}
-
 // dw[co][ci][tap] (+)= sum_s slab[s][co][tap][ci].  One workgroup per (co, tap, 32-channel chunk):
 // 32 channel lanes x 8 slab lanes, slabs summed in a fixed order (bitwise reproducible).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab,
                                                            float* __restrict__ dw, int nslab, int Co, int Ci,
                                                            int Co_pad, int Ci_pad, int taps,
-                                                           int accumulate) {
+                                                           int accumulate, int nmain,
+                                                           const float* __restrict__ bias_slab,
+                                                           float* __restrict__ db) {
   __shared__ float red[8][32];
+  if ((int)blockIdx.x >= nmain) {
+    // trailing workgroups: db[co] (+)= sum_s bias_slab[s][co], slabs in a fixed order
+    const int co = (blockIdx.x - nmain) * 256 + threadIdx.x;
+    if (co < Co) {
+      float s = 0.f;
+      for (int i = 0; i < nslab; ++i) s += bias_slab[(long)i * Co_pad + co];
+      db[co] = accumulate ? db[co] + s : s;
+    }
+    return;
+  }
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int nchunk = Ci_pad / 32;
   int t = blockIdx.x;
@@ -593,14 +595,10 @@ static int wgrad_impl(const void* in, int ldin, const void* dy, int lddy, float*
     rc = ks == 3 ? launch_wgrad<float, 3>(a, p, stream) : launch_wgrad<float, 1>(a, p, stream);
   if (rc != UNETK_OK) return rc;
   const long nblocks = (long)Co * ks * ks * (p.Ci_pad / 32);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)nblocks), dim3(256), 0, stream, a.slab, dw,
-                     p.nsplit, Co, Ci, p.Co_pad, p.Ci_pad, ks * ks, accumulate);
+  const long nbias = dbias ? cdiv(Co, 256) : 0;      // trailing workgroups sum the bias slabs
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(nblocks + nbias)), dim3(256), 0, stream, a.slab, dw,
+                     p.nsplit, Co, Ci, p.Co_pad, p.Ci_pad, ks * ks, accumulate, (int)nblocks, a.bias_slab, dbias);
   UNETK_CHECK_LAUNCH();
-  if (dbias) {
-    hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3(cdiv(Co, 256)), dim3(256), 0, stream, a.bias_slab, dbias,
-                       p.nsplit, Co, p.Co_pad, accumulate);
-    UNETK_CHECK_LAUNCH();
-  }
   return UNETK_OK;
 }
 

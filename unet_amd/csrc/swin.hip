@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 // ---- LayerNorm with a group of G lanes per token (G = 16, 32 or 64: the smallest that holds the
 // token's 16-byte vectors in at most LN_MAXV per lane).  A 96-channel bf16 token is 12 vectors: one
 // wave takes four tokens instead of one, every vector is read once and kept in registers, and the
-// group reductions stay inside a DPP row for G = 16.
+// group reductions stay inside a DPP row for G = 16.  V = vectors per lane (registers are sized by it).
 constexpr int LN_MAXV = 6;
 
 template <int G> __device__ __forceinline__ float group_sum(float v) {
@@ -141,7 +141,7 @@ template <int G> __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
-template <typename T, int G>
+template <typename T, int G, int V>
 __global__ __launch_bounds__(256) void layernorm_fwd_group_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                                   const float* __restrict__ gamma,
                                                                   const float* __restrict__ beta,
@@ -154,10 +154,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_group_kernel(const T* __res
   const long tok = (long)blockIdx.x * (256 / G) + threadIdx.x / G;
   const bool live = tok < ntok;                      // (dead groups still take part in the shuffles)
   const T* xr = x + (live ? tok : 0) * C;
-  Vec16<T> v[LN_MAXV];
+  Vec16<T> v[V];
   float s = 0.f;
 #pragma unroll
-  for (int k = 0; k < LN_MAXV; ++k) {
+  for (int k = 0; k < V; ++k) {
     const int cg = k * G + gl;
     if (cg < CG) {
       v[k] = load16(xr + cg * E);
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_group_kernel(const T* __res
   const float mean = group_sum<G>(s) / (float)C;
   float q = 0.f;
 #pragma unroll
-  for (int k = 0; k < LN_MAXV; ++k)
+  for (int k = 0; k < V; ++k)
     if (k * G + gl < CG) {
 #pragma unroll
       for (int e = 0; e < E; ++e) {
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_group_kernel(const T* __res
   const float rstd = 1.0f / sqrtf(group_sum<G>(q) / (float)C + eps);
   if (!live) return;
 #pragma unroll
-  for (int k = 0; k < LN_MAXV; ++k) {
+  for (int k = 0; k < V; ++k) {
     const int cg = k * G + gl;
     if (cg < CG) {
       Vec16<T> o;
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_group_kernel(const T* __res
 // workgroup's share of dgamma = sum dy*xhat and dbeta = sum dy: workgroup b walks tokens
 // [b*chunk, (b+1)*chunk), each lane keeps the sums of its channel vectors in registers, the token
 // groups of the workgroup are added through LDS in a fixed order -> partials[b][2][C].
-template <typename T, int G>
+template <typename T, int G, int V>
 __global__ __launch_bounds__(256) void layernorm_bwd_group_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                                   const float* __restrict__ gamma,
                                                                   const float* __restrict__ mean,
@@ -215,9 +215,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_group_kernel(const T* __res
   const long pbeg = (long)blockIdx.x * chunk;
   long pend = pbeg + chunk;
   if (pend > ntok) pend = ntok;
-  float ag[LN_MAXV][E], ab[LN_MAXV][E];
+  float ag[V][E], ab[V][E];
 #pragma unroll
-  for (int k = 0; k < LN_MAXV; ++k)
+  for (int k = 0; k < V; ++k)
 #pragma unroll
     for (int e = 0; e < E; ++e) ag[k][e] = ab[k][e] = 0.f;
   for (long t0 = pbeg; t0 < pend; t0 += TPW) {        // (uniform trip count: the shuffles need whole waves)
@@ -225,10 +225,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_group_kernel(const T* __res
     const bool live = tok < pend;
     const long tk = live ? tok : pbeg;
     const float mu = mean[tk], rs = rstd[tk];
-    Vec16<T> dv[LN_MAXV], xv[LN_MAXV];
+    Vec16<T> dv[V], xv[V];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k) {
+    for (int k = 0; k < V; ++k) {
       const int cg = k * G + gl;
       if (cg < CG) {
         dv[k] = load16(dy + tk * C + cg * E);
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_group_kernel(const T* __res
     s2 = group_sum<G>(s2) / (float)C;
     if (live) {
 #pragma unroll
-      for (int k = 0; k < LN_MAXV; ++k) {
+      for (int k = 0; k < V; ++k) {
         const int cg = k * G + gl;
         if (cg < CG) {
           Vec16<T> av = zero16<T>();
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_group_kernel(const T* __res
   }
   if (partials == nullptr) return;
 #pragma unroll
-  for (int k = 0; k < LN_MAXV; ++k) {
+  for (int k = 0; k < V; ++k) {
     if (k * G >= CG) break;                             // (uniform)
     __syncthreads();
 #pragma unroll
@@ -917,12 +917,16 @@ int unetk_layernorm_fwd(const void* x, void* y, const float* gamma, const float*
   CHECK_DT("layernorm_fwd", dtype);
   UNETK_CHECK_ARG(C % VEC_OF(dtype) == 0, "layernorm_fwd: C=%d not a multiple of %d", C, VEC_OF(dtype));
   const int G = ln_group(C / VEC_OF(dtype));
-#define LN_FWD(G_)                                                                                              \
-  DISPATCH_T(dtype, hipLaunchKernelGGL((layernorm_fwd_group_kernel<T, G_>), dim3(cdiv(ntok, 256 / G_)), dim3(256), 0, \
-                                       stream, (const T*)x, (T*)y, gamma, beta, mean, rstd, (long)ntok, C, eps))
-  if (G == 16) LN_FWD(16);
-  else if (G == 32) LN_FWD(32);
-  else if (G == 64) LN_FWD(64);
+  const int V = G ? cdiv(C / VEC_OF(dtype), G) : 0;
+#define LN_FWD(G_, V_)                                                                                          \
+  DISPATCH_T(dtype, hipLaunchKernelGGL((layernorm_fwd_group_kernel<T, G_, V_>), dim3(cdiv(ntok, 256 / G_)), dim3(256), \
+                                       0, stream, (const T*)x, (T*)y, gamma, beta, mean, rstd, (long)ntok, C, eps))
+  if (G == 16) LN_FWD(16, 1);
+  else if (G == 32) LN_FWD(32, 1);
+  else if (G == 64 && V == 1) LN_FWD(64, 1);
+  else if (G == 64 && V == 2) LN_FWD(64, 2);
+  else if (G == 64 && V == 3) LN_FWD(64, 3);
+  else if (G == 64) LN_FWD(64, 6);
   else   // more vectors per token than the grouped kernel keeps in registers: one wave per token
     DISPATCH_T(dtype, hipLaunchKernelGGL(layernorm_fwd_kernel<T>, dim3(cdiv(ntok, 4)), dim3(256), 0, stream,
                                          (const T*)x, (T*)y, gamma, beta, mean, rstd, (long)ntok, C, eps));
@@ -946,13 +950,17 @@ int unetk_layernorm_bwd(const void* dy, const void* x, const float* gamma, const
   const bool want_sums = dgamma || dbeta;
   if (G != 0) {
     // dx and the workgroups' dgamma / dbeta partials in one pass over dy and x
-#define LN_BWD(G_)                                                                                             \
-  DISPATCH_T(dtype, hipLaunchKernelGGL((layernorm_bwd_group_kernel<T, G_>), dim3(cdiv(ntok, chunk)), dim3(256), 0,   \
-                                       stream, (const T*)dy, (const T*)x, gamma, mean, rstd, (const T*)add, (T*)dx,  \
-                                       (long)ntok, C, chunk, want_sums ? partials : nullptr))
-    if (G == 16) LN_BWD(16);
-    else if (G == 32) LN_BWD(32);
-    else LN_BWD(64);
+    const int V = cdiv(C / VEC_OF(dtype), G);
+#define LN_BWD(G_, V_)                                                                                         \
+  DISPATCH_T(dtype, hipLaunchKernelGGL((layernorm_bwd_group_kernel<T, G_, V_>), dim3(cdiv(ntok, chunk)), dim3(256), \
+                                       0, stream, (const T*)dy, (const T*)x, gamma, mean, rstd, (const T*)add,   \
+                                       (T*)dx, (long)ntok, C, chunk, want_sums ? partials : nullptr))
+    if (G == 16) LN_BWD(16, 1);
+    else if (G == 32) LN_BWD(32, 1);
+    else if (V == 1) LN_BWD(64, 1);
+    else if (V == 2) LN_BWD(64, 2);
+    else if (V == 3) LN_BWD(64, 3);
+    else LN_BWD(64, 6);
 #undef LN_BWD
     UNETK_CHECK_LAUNCH();
     if (want_sums) {
