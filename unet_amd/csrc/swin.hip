@@ -887,7 +887,7 @@ inline int ln_group(int cg) {
 }
 
 inline int tok_blocks(long ntok) {
-  long n = (ntok + 63) / 64;
+  long n = (ntok + 15) / 16;       // at least 16 tokens per workgroup, at most 1024 workgroups
   if (n > 1024) n = 1024;
   if (n < 1) n = 1;
   return (int)n;
