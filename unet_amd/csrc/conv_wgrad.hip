@@ -480,6 +480,9 @@ struct WgradPlan {
 WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int dtype, int ks) {
   WgradPlan p;
   p.mt = (Co % 48 == 0) ? 3 : ((Co % 64 == 0 || Co > 48) ? 4 : (Co > 32 ? 3 : 2));
+  // 3x3: 64-channel row blocks where they divide Co: fewer passes over the input halo per output,
+  // and more MFMAs per fragment read (not at <= 16-pixel rows, where the wider tile measured slower)
+  if (ks == 3 && Co % 64 == 0 && W > 16) p.mt = 4;
   p.tw = (W <= 16) ? 16 : 32;
   // 3x3: 32 input channels per workgroup (two waves across the channels, four along K); the
   // 64-channel form only for 1x1 shapes, where it wastes no padding or the shape is bandwidth-bound
