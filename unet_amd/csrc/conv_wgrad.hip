@@ -493,6 +493,7 @@ WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int dtype, int ks) {
       (Ci % 64 == 0 || (Ci > 256 && (Ci % 64) > 32) || (low_intensity && Ci > 32)))
     p.nwn = 4;
   if (ks == 1 && dtype == UNETK_BF16 && Ci >= 64) p.nwn = 1;   // plain GEMM: 4 channel slices per wave
+  if (ks == 1 && p.nwn == 1 && Co % 64 == 0) p.mt = 4;     // same for the sliced 1x1 form (64 x 64 outputs per workgroup)
   p.nwk = 8 / p.nwn;
   p.tpix = dtype == UNETK_BF16 ? 256 : 128;
   p.tr = p.tpix / p.tw;
