@@ -9,7 +9,8 @@
 // registers: per 16 taps it reads 16 new inputs from LDS and issues 256 FMAs, so the pass is bound
 // by the double-precision FMA rate, not by LDS or HBM.  The weights are read through the scalar
 // path (uniform index).  Lanes of a wave run along the ROWS of the tile and the row pitch is an
-// odd number of 8-byte words, so the LDS reads are conflict-free.
+// odd number of 8-byte words, so the LDS reads are conflict-free.  The tile is sized by the radius
+// (dynamic LDS): 66 KB at radius 124, two workgroups per CU.
 #include "common.h"
 
 namespace {
@@ -18,7 +19,8 @@ constexpr int FT_ROWS = 16;       // rows per workgroup
 constexpr int FT_COLS = 256;      // output columns per workgroup
 constexpr int FT_R = 16;          // outputs per thread (and taps per register block)
 constexpr int FT_RMAX = 256;      // largest radius (sigma up to 64 pixels)
-constexpr int FT_PITCH = FT_COLS + 2 * FT_RMAX + FT_R + 1;   // doubles per staged row (odd)
+// doubles per staged row: the columns the register windows read, plus one so the pitch is odd
+__host__ __device__ inline int ft_pitch(int radius) { return FT_COLS + (2 * radius + 1 + FT_R - 1) / FT_R * FT_R + 1; }
 
 // scipy 'reflect' (half-sample symmetric): ... c b a | a b c d | d c b ...
 __device__ __forceinline__ int reflect_index(int i, int n) {
@@ -32,7 +34,8 @@ __device__ __forceinline__ int reflect_index(int i, int n) {
 __global__ __launch_bounds__(256) void gauss_rows_kernel(const double* __restrict__ in, double* __restrict__ out,
                                                          const double* __restrict__ nan_src, int rows, int cols,
                                                          const double* __restrict__ wpad, int radius, int zero_nan) {
-  __shared__ double tile[FT_ROWS * FT_PITCH];
+  extern __shared__ double tile[];                        // FT_ROWS x pitch, sized by the radius at launch
+  const int FT_PITCH = ft_pitch(radius);
   const int x0 = blockIdx.x * FT_COLS, y0 = blockIdx.y * FT_ROWS;
   const int width = FT_COLS + 2 * radius;                 // staged inputs that carry weight
   const int nblk = (2 * radius + 1 + FT_R - 1) / FT_R;    // tap blocks
@@ -110,7 +113,16 @@ int unetk_gauss_rows_f64(const double* in, double* out, const double* nan_src, i
   UNETK_CHECK_ARG(radius >= 0 && radius <= FT_RMAX, "gauss_rows: radius %d (0..%d)", radius, FT_RMAX);
   dim3 grid((unsigned)cdiv(cols, FT_COLS), (unsigned)cdiv(rows, FT_ROWS));
   UNETK_CHECK_ARG(grid.y < 65536u, "gauss_rows: too many rows");
-  hipLaunchKernelGGL(gauss_rows_kernel, grid, dim3(256), 0, stream, in, out, nan_src, rows, cols, wpad, radius,
+  const size_t lds = (size_t)FT_ROWS * ft_pitch(radius) * sizeof(double);
+  if (lds > 64 * 1024) {                                  // opt in on the current device (cheap, idempotent)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_rows_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      unetk_set_error("gauss_rows: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+      return UNETK_EHIP;
+    }
+  }
+  hipLaunchKernelGGL(gauss_rows_kernel, grid, dim3(256), lds, stream, in, out, nan_src, rows, cols, wpad, radius,
                      zero_nan);
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
