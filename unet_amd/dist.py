@@ -28,33 +28,26 @@ class GradReducer:
             size += n
         if cur:
             self.buckets.append(cur)
-        self._flat = [None] * len(self.buckets)
 
     def allreduce(self):
-        """Average .grad of every parameter over the ranks (in place).  Asynchronous per bucket:
-        the copy-in of bucket k+1 overlaps the collective of bucket k."""
+        """Average .grad of every parameter over the ranks.  Asynchronous per bucket: the copy-in of
+        bucket k+1 overlaps the collective of bucket k.  Afterwards every .grad is a view into its
+        bucket's (fresh) flat buffer: one scaling kernel per bucket, no copy back per parameter."""
         if self.world == 1:
             return
         works = []
-        for bi, bucket in enumerate(self.buckets):
+        for bucket in self.buckets:
             grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in bucket]
-            n = sum(g.numel() for g in grads)
-            flat = self._flat[bi]
-            if flat is None or flat.numel() != n or flat.device != grads[0].device:
-                flat = self._flat[bi] = torch.empty(n, dtype=torch.float32, device=grads[0].device)
-            torch.cat([g.reshape(-1).float() for g in grads], out=flat)
+            flat = torch.cat([g.reshape(-1).float() for g in grads])
             works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, bucket))
         inv = 1.0 / self.world
         for work, flat, bucket in works:
             work.wait()
+            flat.mul_(inv)
             off = 0
             for p in bucket:
                 n = p.numel()
-                g = flat[off:off + n].view_as(p) * inv
-                if p.grad is None:
-                    p.grad = g.clone()
-                else:
-                    p.grad.copy_(g)
+                p.grad = flat[off:off + n].view_as(p)
                 off += n
 
 
