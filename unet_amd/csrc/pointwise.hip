@@ -50,8 +50,18 @@ __global__ __launch_bounds__(256) void bn_prereduce_kernel(float* partials, int 
   long r1 = r0 + G;
   if (r1 > nparts) r1 = nparts;
   if (r1 - r0 < 2) return;
-  double s = 0.0;
-  for (long r = r0; r < r1; ++r) s += (double)partials[r * ncol + col];
+  // eight independent chains (rows r0+k, r0+k+8, ...) keep eight loads in flight; combined in a fixed order
+  double c8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  long r = r0;
+  for (; r + 8 <= r1; r += 8) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = partials[(r + k) * ncol + col];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c8[k] += (double)v[k];
+  }
+  for (int k = 0; r < r1; ++r, ++k) c8[k] += (double)partials[r * ncol + col];
+  const double s = ((c8[0] + c8[1]) + (c8[2] + c8[3])) + ((c8[4] + c8[5]) + (c8[6] + c8[7]));
   const float hi = (float)s;
   partials[r0 * ncol + col] = hi;
   partials[(r0 + 1) * ncol + col] = (float)(s - (double)hi);
