@@ -718,22 +718,34 @@ __global__ __launch_bounds__(256) void head1x1_fwd_kernel(const T* __restrict__ 
                                                           const float* __restrict__ bias,
                                                           float* __restrict__ out, long npix, long hw, int C,
                                                           int Co) {
+  // Threads are (pixel lane, channel group): consecutive threads read consecutive 16-byte vectors of a
+  // pixel row, so the loads are coalesced; a pixel's partial dot products meet in LDS and its first
+  // thread adds them in channel order.
   constexpr int E = Vec16<T>::N;
-  extern __shared__ float wl[];   // [Co][C]
+  extern __shared__ float wl[];              // [Co][C] weights, then [256] partial sums
+  float* red = wl + Co * C;
   for (int i = threadIdx.x; i < Co * C; i += blockDim.x) wl[i] = w[i];
+  const int CG = C / E;
+  const int lanes = 256 / CG;
+  const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
+  const long p = (long)blockIdx.x * lanes + pl;
+  const bool live = pl < lanes && p < npix;
+  Vec16<T> v = zero16<T>();
+  if (live) v = load16(x + p * ldx + cg * E);
   __syncthreads();
-  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= npix) return;
-  const int b = p / hw;
-  const long r = p - (long)b * hw;
   for (int o = 0; o < Co; ++o) {
-    float s = bias ? bias[o] : 0.f;
-    for (int c0 = 0; c0 < C; c0 += E) {
-      Vec16<T> v = load16(x + p * ldx + c0);
+    float s = 0.f;
 #pragma unroll
-      for (int e = 0; e < E; ++e) s += to_f32(v.v[e]) * wl[o * C + c0 + e];
+    for (int e = 0; e < E; ++e) s += to_f32(v.v[e]) * wl[o * C + cg * E + e];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (live && cg == 0) {
+      float t = bias ? bias[o] : 0.f;
+      for (int k = 0; k < CG; ++k) t += red[threadIdx.x + k];
+      const int b = p / hw;
+      out[((long)b * Co + o) * hw + (p - (long)b * hw)] = t;
     }
-    out[((long)b * Co + o) * hw + r] = s;
+    __syncthreads();
   }
 }
 
@@ -972,9 +984,12 @@ int unetk_head1x1_fwd(const void* x, int ldx, const float* w, const float* bias,
   CHECK_DTYPE("head1x1_fwd", dtype);
   CHECK_VEC("head1x1_fwd", dtype, C);
   UNETK_CHECK_ARG((long)Co * C * 4 <= 48 * 1024, "head1x1_fwd: weight (%d x %d) too large", Co, C);
+  const int E = dtype == UNETK_BF16 ? 8 : 4;
+  UNETK_CHECK_ARG(C / E <= 256, "head1x1_fwd: too many channels (%d)", C);
   const long npix = (long)B * H * W;
-  DISPATCH_T(dtype, hipLaunchKernelGGL(head1x1_fwd_kernel<T>, dim3(cdiv(npix, 256)), dim3(256),
-                                       (size_t)Co * C * 4, stream, (const T*)x, ldx, w, bias, out, npix,
+  const int lanes = 256 / (C / E);           // pixels per workgroup
+  DISPATCH_T(dtype, hipLaunchKernelGGL(head1x1_fwd_kernel<T>, dim3((unsigned)cdiv(npix, lanes)), dim3(256),
+                                       (size_t)(Co * C + 256) * 4, stream, (const T*)x, ldx, w, bias, out, npix,
                                        (long)H * W, C, Co));
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
