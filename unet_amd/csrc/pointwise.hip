@@ -590,6 +590,30 @@ __device__ __forceinline__ void src_index(float scale, int dst, int in_size, int
   l1 = s - (float)i0;
 }
 
+template <typename T>
+__device__ __forceinline__ Vec16<T> bilerp(const Vec16<T>& v00, const Vec16<T>& v01, const Vec16<T>& v10,
+                                           const Vec16<T>& v11, float ly, float lx) {
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  Vec16<T> o;
+#pragma unroll
+  for (int e = 0; e < Vec16<T>::N; ++e)
+    o.v[e] = from_f32<T>(hy * (hx * to_f32(v00.v[e]) + lx * to_f32(v01.v[e])) +
+                         ly * (hx * to_f32(v10.v[e]) + lx * to_f32(v11.v[e])));
+  return o;
+}
+
+// One resized vector: channels [c0, c0+E) of output pixel (y,x); base = low + image offset + c0.
+template <typename T>
+__device__ __forceinline__ Vec16<T> resize_at(const T* __restrict__ base, int h, int w, int C1, int y, int x,
+                                              float sy, float sx) {
+  int y0, y1, x0, x1;
+  float ly, lx;
+  src_index(sy, y, h, y0, y1, ly);
+  src_index(sx, x, w, x0, x1, lx);
+  return bilerp(load16(base + ((long)y0 * w + x0) * C1), load16(base + ((long)y0 * w + x1) * C1),
+                load16(base + ((long)y1 * w + x0) * C1), load16(base + ((long)y1 * w + x1) * C1), ly, lx);
+}
+
 // out[b,y,x, 0:C1] = resize(low)[b,y,x,:], out[b,y,x, C1:C1+C2] = skip[b,y,x,:]
 template <typename T>
 __global__ void upsample_concat_kernel(const T* __restrict__ low, int h, int w, int C1,
@@ -606,26 +630,69 @@ __global__ void upsample_concat_kernel(const T* __restrict__ low, int h, int w, 
   const int y = (p / W) % H;
   const int b = p / ((unsigned)W * H);
   Vec16<T> o;
-  if (cg < CG1) {
-    int y0, y1, x0, x1;
-    float ly, lx;
-    src_index(sy, y, h, y0, y1, ly);
-    src_index(sx, x, w, x0, x1, lx);
-    const int c0 = cg * E;
-    const T* base = low + (long)b * h * w * C1 + c0;
-    Vec16<T> v00 = load16(base + ((long)y0 * w + x0) * C1);
-    Vec16<T> v01 = load16(base + ((long)y0 * w + x1) * C1);
-    Vec16<T> v10 = load16(base + ((long)y1 * w + x0) * C1);
-    Vec16<T> v11 = load16(base + ((long)y1 * w + x1) * C1);
-    const float hy = 1.f - ly, hx = 1.f - lx;
-#pragma unroll
-    for (int e = 0; e < E; ++e)
-      o.v[e] = from_f32<T>(hy * (hx * to_f32(v00.v[e]) + lx * to_f32(v01.v[e])) +
-                           ly * (hx * to_f32(v10.v[e]) + lx * to_f32(v11.v[e])));
-  } else {
+  if (cg < CG1)
+    o = resize_at(low + (long)b * h * w * C1 + cg * E, h, w, C1, y, x, sy, sx);
+  else
     o = load16(skip + (size_t)p * ldskip + (cg - CG1) * E);
-  }
   store16(out + (size_t)p * C + cg * E, o);
+}
+
+// The exact 2x case (H = 2h, W = 2w): one thread produces the 2x2 output pixels that share the
+// low-resolution pixel (i,j).  Away from the border they read the 3x3 neighbourhood of (i,j): nine
+// loads feed four outputs where the general kernel issues sixteen.  Indices and weights still come
+// from src_index and the arithmetic is the general kernel's, so both give the same bits.
+template <typename T>
+__global__ void upsample2x_concat_kernel(const T* __restrict__ low, int h, int w, int C1,
+                                         const T* __restrict__ skip, int ldskip, int C2, T* __restrict__ out,
+                                         int B) {
+  constexpr int E = Vec16<T>::N;
+  const int C = C1 + C2, CG1 = C1 / E;
+  const int CG = skip != nullptr ? C / E : CG1;
+  const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;     // the host checks that it fits 31 bits
+  if (idx >= (unsigned)B * h * w * CG) return;
+  const int cg = idx % CG;
+  const unsigned p = idx / CG;
+  const int j = p % w;
+  const int i = (p / w) % h;
+  const int b = p / ((unsigned)w * h);
+  const int H = 2 * h, W = 2 * w;
+  const size_t opix = ((size_t)b * H + 2 * i) * W + 2 * j;       // output pixel (2i, 2j)
+  if (cg >= CG1) {
+    const int c0 = (cg - CG1) * E;
+    Vec16<T> s[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] = load16(skip + (opix + (size_t)(k >> 1) * W + (k & 1)) * ldskip + c0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) store16(out + (opix + (size_t)(k >> 1) * W + (k & 1)) * C + cg * E, s[k]);
+    return;
+  }
+  const T* base = low + (long)b * h * w * C1 + cg * E;
+  T* o = out + opix * C + cg * E;
+  if (i >= 1 && i < h - 1 && j >= 1 && j < w - 1) {
+    // output row 2i+a reads low rows (i-1+a, i+a), output column 2j+c reads low columns (j-1+c, j+c)
+    Vec16<T> v[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) v[r][q] = load16(base + ((long)(i - 1 + r) * w + (j - 1 + q)) * C1);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      int t0, t1;
+      float ly;
+      src_index(0.5f, 2 * i + a, h, t0, t1, ly);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float lx;
+        src_index(0.5f, 2 * j + c, w, t0, t1, lx);
+        store16(o + ((size_t)a * W + c) * C, bilerp(v[a][c], v[a][c + 1], v[a + 1][c], v[a + 1][c + 1], ly, lx));
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      store16(o + ((size_t)(k >> 1) * W + (k & 1)) * C,
+              resize_at(base, h, w, C1, 2 * i + (k >> 1), 2 * j + (k & 1), 0.5f, 0.5f));
+  }
 }
 
 // dlow[b,i,j,:] = sum over output pixels (y,x) that read (i,j) of wy*wx*dout[b,y,x,:] (gather form)
@@ -955,9 +1022,15 @@ int unetk_upsample_concat_fwd(const void* low, int h, int w, int C1, const void*
   const float sy = (float)h / (float)H, sx = (float)w / (float)W;
   const long total = (long)B * H * W * ((skip ? C1 + C2 : C1) / E);
   UNETK_CHECK_ARG(total < (1L << 31), "upsample_concat_fwd: tensor too large");
-  DISPATCH_T(dtype, hipLaunchKernelGGL(upsample_concat_kernel<T>, dim3(cdiv(total, 256)), dim3(256), 0,
-                                       stream, (const T*)low, h, w, C1, (const T*)skip, ldskip, C2, (T*)out,
-                                       B, H, W, sy, sx));
+  if (H == 2 * h && W == 2 * w) {
+    const long quads = total / 4;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(upsample2x_concat_kernel<T>, dim3(cdiv(quads, 256)), dim3(256), 0,
+                                         stream, (const T*)low, h, w, C1, (const T*)skip, ldskip, C2, (T*)out, B));
+  } else {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(upsample_concat_kernel<T>, dim3(cdiv(total, 256)), dim3(256), 0,
+                                         stream, (const T*)low, h, w, C1, (const T*)skip, ldskip, C2, (T*)out,
+                                         B, H, W, sy, sx));
+  }
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }
