@@ -161,12 +161,14 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
   // swz() looks at pixel bit 2 only.  Issuing a piece then costs two 32-bit operations and a
   // select instead of divisions and multiplies between the MFMAs.
   constexpr int HPW = (HINSTR + 3) / 4;                 // halo pieces per wave (at most)
+  // (the fp32 four-workgroups-per-CU variant has no registers to spare for the table: it recomputes)
+  constexpr bool HTAB = HDB || sizeof(T) == 2;
   const int slot0 = ((lane & 3) ^ swz(lane >> 2)) * EPP;
   const unsigned rows_left = (KS == 3) ? 0u : (unsigned)((npix - p0 < 256) ? (npix - p0) : 256);
   int hp_off[HPW];
   bool hp_in[HPW];
 #pragma unroll
-  for (int k = 0; k < (HDB ? HPW : 0); ++k) {
+  for (int k = 0; k < (HTAB ? HPW : 0); ++k) {
     const int pix = (wave + 4 * k) * 16 + (lane >> 2);
     if (KS == 3) {
       const int hy = pix / HALO, hx = pix - hy * HALO;
@@ -184,8 +186,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     const int c0 = ch * KC;
     const T* base = halo_base + c0;
     const int climit = a.Ci - c0;                         // channel slots below this exist
-    if constexpr (!HDB) {
-      // the 4-workgroups-per-CU variant has no registers to spare for the tables: recompute
+    if constexpr (!HTAB) {
       for (int i = wave; i < HINSTR; i += 4) {
         const int part = i * 64 + lane;
         const int pix = part >> 2;
@@ -439,20 +440,32 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     return (pixbase[i] + 4 * pg + r) < npix;
   };
 
+  const bool tile_full = (KS == 3) ? (y0 + 16 <= a.H && x0 + 16 <= a.W) : (p0 + 256 <= npix);
   __syncthreads();   // every wave is done reading the operand tiles: LDS is reused from here on
   if (a.stats != nullptr) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       float s = 0.f, q = 0.f;
+      if (tile_full) {               // (uniform) no per-value masks away from the image border
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (pixel_valid(i, r)) {
+          for (int r = 0; r < 4; ++r) {
             const float v = acc[i][j][r];
             s += v;
             q += v * v;
           }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (pixel_valid(i, r)) {
+              const float v = acc[i][j][r];
+              s += v;
+              q += v * v;
+            }
+      }
       s += __shfl_xor(s, 16, 64);
       s += __shfl_xor(s, 32, 64);
       q += __shfl_xor(q, 16, 64);
@@ -541,29 +554,64 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
 
   T* stage = reinterpret_cast<T*>(lds) + wave * 16 * BN;
   constexpr int PPP = BN / EPP;            // 16-byte parts per staged pixel
+  // Store pass: the staged 16 x BN tile leaves as 16-byte parts, lane -> (pixel pc, part cp).  What
+  // does not depend on the row tile is computed once: the part's place in the staging tile, its
+  // element offset from the row tile's first pixel in the destination, and whether it exists.
+  constexpr int NIT = (16 * PPP + 63) / 64;
+  T* obase = out;
+  int ldo = a.ldout, oc0 = n0;
+  if (a.out2 != nullptr && n0 >= a.split) {
+    obase = reinterpret_cast<T*>(a.out2);
+    ldo = a.ldout2;
+    oc0 = n0 - a.split;
+  }
+  int st_off[NIT], g_off[NIT], st_pc[NIT];
+  bool st_ok[NIT];
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    const int part = lane + 64 * k;
+    const int pc = part / PPP, cp = part - pc * PPP;
+    st_pc[k] = pc;
+    st_off[k] = pc * BN + cp * EPP;
+    g_off[k] = pc * ldo + oc0 + cp * EPP;
+    st_ok[k] = part < 16 * PPP && n0 + cp * EPP < a.Co && (KS == 3 ? (x0 + pc) < a.W : true);
+  }
+  // The activation is uniform: one branch per row tile, not one per value (GELU: per 4 values, fenced,
+  // so that the compiler does not interleave dozens of erf expansions and their temporaries).
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     if (i > 0) __syncthreads();
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = acc[i][j][r] * esc[j] + esh[j];
-        if (a.act == 1) v = fmaxf(v, 0.f);
-        else if (a.act == 2) v = gelu_erf(v);
-        stage[(4 * pg + r) * BN + j * 16 + cl] = from_f32<T>(v);
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = acc[i][j][r] * esc[j] + esh[j];
+    if (a.act == 1) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaxf(acc[i][j][r], 0.f);
+    } else if (a.act == 2) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = gelu_erf(acc[i][j][r]);
+        __builtin_amdgcn_sched_barrier(0);
       }
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) stage[(4 * pg + r) * BN + j * 16 + cl] = from_f32<T>(acc[i][j][r]);
     __syncthreads();
-    for (int part = lane; part < 16 * PPP; part += 64) {
-      const int pc = part / PPP, cp = part - pc * PPP;
-      const int c = n0 + cp * EPP;
-      bool ok;
-      long p = pixbase[i] + pc;
-      if (KS == 3) ok = rowvalid[i] && (x0 + pc) < a.W;
-      else ok = p < npix;
-      if (ok && c < a.Co) {
-        Vec16<T> v = load16(stage + pc * BN + cp * EPP);
+    T* orow = obase + pixbase[i] * ldo;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const bool ok = st_ok[k] && (KS == 3 ? rowvalid[i] : (unsigned)((4 * wave + i) * 16 + st_pc[k]) < rows_left);
+      if (ok) {
+        Vec16<T> v = load16(stage + st_off[k]);
         if (a.resid != nullptr) {
+          const long p = pixbase[i] + st_pc[k];
+          const int c = n0 + st_off[k] - st_pc[k] * BN;
           const T* rs = reinterpret_cast<const T*>(a.resid) + p * a.ldres + c;
           Vec16<T> rv = load16(rs);
           float keep = 1.f;
@@ -572,10 +620,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
           for (int e = 0; e < EPP; ++e)
             v.v[e] = from_f32<T>(to_f32(rv.v[e]) + keep * to_f32(v.v[e]));
         }
-        if (a.out2 != nullptr && n0 >= a.split)
-          store16(reinterpret_cast<T*>(a.out2) + p * a.ldout2 + (c - a.split), v);
-        else
-          store16(out + p * a.ldout + c, v);
+        store16(orow + g_off[k], v);
       }
     }
   }
