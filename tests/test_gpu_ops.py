@@ -86,6 +86,26 @@ def test_conv_fwd_dgrad_wgrad(dt, shape):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(144, 96), (96, 48), (64, 32)])
+def test_conv_split_outputs(dt, shape):
+    """One conv, two dense results: channels [0,split) and [split,Co) (the data gradient of a
+    concat-consuming conv leaves as the gradients of its two inputs), odd image sizes."""
+    from unet_amd import ops
+    Co, split = shape
+    B, H, W, Ci = 2, 21, 19, 16
+    x = rnd((B, Ci, H, W), 31, dt)
+    w = rnd((Co, Ci, 3, 3), 32, dt, 0.1)
+    ref = F.conv2d(x, w, None, padding=1)
+    pw = ops.PackedConv(w.cuda(), dt)
+    assert split % pw.bn == 0
+    (ya, yb), _ = ops.conv_fwd(nhwc(x, dt), pw, split=split)
+    assert ya.shape[-1] == split and yb.shape[-1] == Co - split
+    whole, _ = ops.conv_fwd(nhwc(x, dt), pw)
+    assert torch.equal(torch.cat((ya, yb), -1), whole)
+    assert rel(nchw(whole), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 def test_conv_epilogue_affine_relu_residual(dt):
     from unet_amd import ops
     B, H, W, Ci, Co = 2, 19, 21, 16, 32
