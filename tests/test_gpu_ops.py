@@ -86,7 +86,7 @@ def test_conv_fwd_dgrad_wgrad(dt, shape):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("shape", [(144, 96), (96, 48), (64, 32)])
+@pytest.mark.parametrize("shape", [(144, 96), (144, 48), (192, 96), (128, 64)])
 def test_conv_split_outputs(dt, shape):
     """One conv, two dense results: channels [0,split) and [split,Co) (the data gradient of a
     concat-consuming conv leaves as the gradients of its two inputs), odd image sizes."""
