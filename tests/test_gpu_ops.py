@@ -236,14 +236,15 @@ def test_head1x1_fwd_bwd(dt, Co):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-def test_layout_roundtrip(dt):
+@pytest.mark.parametrize("C", [1, 4, 5, 11])      # one 16-byte vector per pixel, and wider
+def test_layout_roundtrip(dt, C):
     from unet_amd import ops
-    x = rnd((2, 5, 7, 9), 17, dt)
+    x = rnd((3, C, 7, 9), 17, dt)
     h = ops.nchw_to_nhwc(x.cuda(), dt)
     assert h.shape[-1] % (8 if dt == torch.bfloat16 else 4) == 0
-    assert torch.equal(h[..., :5].float().cpu(), x.permute(0, 2, 3, 1))
-    assert torch.count_nonzero(h[..., 5:]) == 0
-    assert torch.equal(ops.nhwc_to_nchw(h, 5).cpu(), x)
+    assert torch.equal(h[..., :C].float().cpu(), x.permute(0, 2, 3, 1))
+    assert torch.count_nonzero(h[..., C:]) == 0
+    assert torch.equal(ops.nhwc_to_nchw(h, C).cpu(), x)
 
 
 def test_bad_arguments_raise():

@@ -27,6 +27,23 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict
   dst[idx] = from_f32<T>(c < C ? src[((long)b * C + c) * H * W + hw] : 0.f);
 }
 
+// The same for a destination pixel of exactly one 16-byte vector (network inputs: a few planes,
+// padded to 8 bf16 / 4 fp32 channels): one thread per pixel, so each plane is read as consecutive
+// floats across the wave and the pixel leaves as one vector store.
+template <typename T>
+__global__ void nchw_to_nhwc_vec_kernel(const float* __restrict__ src, T* __restrict__ dst, long npix, int C,
+                                        long hw) {
+  constexpr int E = Vec16<T>::N;
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npix) return;
+  const long b = p / hw, r = p - b * hw;
+  const float* s = src + b * C * hw + r;
+  Vec16<T> o;
+#pragma unroll
+  for (int e = 0; e < E; ++e) o.v[e] = from_f32<T>(e < C ? s[(long)e * hw] : 0.f);
+  store16(dst + p * E, o);
+}
+
 template <typename T>
 __global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int B, int C,
                                     int H, int W, int ld) {
@@ -874,8 +891,14 @@ int unetk_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, 
   UNETK_CHECK_ARG(src && dst && ld >= C, "nchw_to_nhwc: bad arguments");
   CHECK_DTYPE("nchw_to_nhwc", dtype);
   const long total = (long)B * H * W * ld;
-  DISPATCH_T(dtype, hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(cdiv(total, 256)), dim3(256), 0, stream,
-                                       src, (T*)dst, B, C, H, W, ld));
+  if (ld == (dtype == UNETK_BF16 ? 8 : 4)) {
+    const long npix = (long)B * H * W;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(nchw_to_nhwc_vec_kernel<T>, dim3(cdiv(npix, 256)), dim3(256), 0, stream,
+                                         src, (T*)dst, npix, C, (long)H * W));
+  } else {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(cdiv(total, 256)), dim3(256), 0, stream,
+                                         src, (T*)dst, B, C, H, W, ld));
+  }
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }
