@@ -496,11 +496,23 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
   if constexpr (KS == 3 && FUSE) {
     // Inference-time fusions on the values as they are stored (activation applied, rounded to T):
     // a lane holds pixels (row 4*wave+i, column 4*pg+r), i.e. whole 2x2 quads, for its channels.
-    auto val = [&](int i, int j, int r) -> float {
-      float v = acc[i][j][r] * esc[j] + esh[j];
-      if (a.act == 1) v = fmaxf(v, 0.f);       // (the host admits only none / ReLU here)
-      return to_f32(from_f32<T>(v));
-    };
+    // (scale, shift and the activation are applied in place first, under one uniform branch; the
+    // host admits only none / ReLU here)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = acc[i][j][r] * esc[j] + esh[j];
+    if (a.act == 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaxf(acc[i][j][r], 0.f);
+    }
+    auto val = [&](int i, int j, int r) -> float { return to_f32(from_f32<T>(acc[i][j][r])); };
     if (a.pooled != nullptr) {
       T* pl = reinterpret_cast<T*>(a.pooled);
       const int PH = a.H >> 1, PW = a.W >> 1;
@@ -581,21 +593,23 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     if (i > 0) __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[i][j][r] = acc[i][j][r] * esc[j] + esh[j];
-    if (a.act == 1) {
+    if constexpr (!(KS == 3 && FUSE)) {        // (the fused variant has applied them above)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaxf(acc[i][j][r], 0.f);
-    } else if (a.act == 2) {
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = acc[i][j][r] * esc[j] + esh[j];
+      if (a.act == 1) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][j][r] = gelu_erf(acc[i][j][r]);
-        __builtin_amdgcn_sched_barrier(0);
+          for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaxf(acc[i][j][r], 0.f);
+      } else if (a.act == 2) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] = gelu_erf(acc[i][j][r]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
 #pragma unroll
