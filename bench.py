@@ -1,25 +1,32 @@
 #!/usr/bin/env python
-"""Headline benchmark: UNet training step (forward + multi-loss + backward) on MI355X.
+"""Benchmark of the hot path on MI355X: UNet training step (headline), Swin-UNet training step and tiled
+large-area prediction.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-One step = one pass of the hot path over one synthetic batch that is already resident in HBM:
-OptimizedUNet(4,1,48) forward, the 'all' multi-loss, backward to every parameter (for N > 1 the
-data-parallel gradient all-reduce over RCCL), global-norm clip and the AdamW update.  Workload = BASELINE config 2: batch 64 of
-4x256x256 patches per GPU, bf16 storage with fp32 accumulation.  Rank 0 prints ONE JSON line.
+With WORLD_SIZE unset and --gpus N > 1 this process only starts N fresh rank processes (before it makes
+any GPU call) and waits for them.  Rank 0 prints ONE JSON line:
 
-The line also carries
-  roofline     - the dominant kernel, the MFMA implicit-GEMM conv with 96-channel blocks (forward and
-                 data-gradient launches): algorithmic FLOPs per launch / average launch duration,
-                 measured with events on the launch stream inside the timed steps, against the
-                 2.5 PFLOP/s dense bf16 peak (plus the same ratio over the whole conv family);
-  cpu_baseline - the CPU oracle (torch fp32) timed on this host on a bounded sample of the same
-                 workload (batch 4, same network and loss).
+  headline  BASELINE config 2: OptimizedUNet(4,1,48) forward, the 'all' multi-loss, backward to every
+            parameter (N > 1: bucketed RCCL all-reduce launched from inside the backward pass), global-norm
+            clip and AdamW; batch 64 of 4x256x256 per GPU, bf16 storage with fp32 accumulation, inputs
+            resident in HBM.  `roofline` is its dominant kernel (MFMA implicit-GEMM conv, 96-channel blocks):
+            algorithmic FLOPs per launch / average launch duration measured with events on the launch
+            stream inside the timed steps, against the 2.5 PFLOP/s dense bf16 peak.
+  "swin"    BASELINE config 3 as the reference trainer runs it (swin_unet_model.py:809-823): SwinUNet
+            forward, bilinear resize of the half-resolution prediction to the 256x256 label, the
+            'tid_gradient' multi-loss, backward, clip, AdamW(1e-4, 0.05).
+  "predict" BASELINE config 4: LargeAreaPredictor over a synthetic 8192x8192 grid, 256-px tiles, stride 128,
+            UNet(4,1,48) eval, Gaussian blend; tile rows sharded over the ranks (strong scaling).
+Each record carries its own `roofline` and, at N = 1, a `cpu_baseline`: the CPU oracle (torch fp32) timed on
+this host on a bounded sample of the same workload.  --workload train|swin|predict runs one of them only.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,15 +37,17 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak of MI355X
 PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
 LOSS_CFG = {   # training_variants.py:119-130 "all" preset
     "loss_combination": "all", "pixel_loss_weight": 1.0, "gradient_loss_weight": 0.3,
     "spectral_loss_weight": 0.2, "pixel_loss_type": "mse", "use_tid_weights": True,
     "tid_weight_scale": 1.0, "gradient_method": "sobel", "spectral_focus_high_freq": True,
     "high_freq_weight_factor": 2.0,
 }
+SWIN_LOSS_CFG = dict(LOSS_CFG, loss_combination="weighted_mse_grad", spectral_loss_weight=0.0)   # 'tid_gradient'
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -46,116 +55,72 @@ def parse():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--workload", default="train", choices=["train", "swin", "predict"],
-                    help="train: UNet step (headline); swin: Swin-UNet step; predict: tiled large-area inference")
+    ap.add_argument("--workload", default="all", choices=["all", "train", "swin", "predict"],
+                    help="all: headline UNet step with the swin and predict records attached; or one of them alone")
     ap.add_argument("--grid", type=int, default=8192, help="predict: side of the synthetic grid")
+    ap.add_argument("--swin-batch", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def make_loss():
+# ---------------------------------------------------------------------------- rank launcher
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def rank_environments(n, port, base=None):
+    """Environment of each of the n rank processes (one per GPU, rendezvous on the loopback address)."""
+    envs = []
+    for r in range(n):
+        e = dict(os.environ if base is None else base)
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                 MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        envs.append(e)
+    return envs
+
+
+def launch_ranks(n, argv):
+    """Start n fresh rank processes of this script and wait for them.  The parent never touches the GPU
+    and replaces no process image; a failing rank ends the others."""
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e)
+             for e in rank_environments(n, free_port())]
+    rc = 0
     try:
-        from unet_amd.losses import MultiLossFunction
-        return MultiLossFunction(LOSS_CFG), "all"
-    except ImportError:
-        return None, "mse"
+        alive = list(procs)
+        while alive:
+            for p in list(alive):
+                r = p.poll()
+                if r is None:
+                    continue
+                alive.remove(p)
+                if r != 0 and rc == 0:
+                    rc = r
+                    for q in alive:
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
-def train_step(model, crit, x, y, w):
-    for p in model.parameters():
-        p.grad = None
-    out = model(x)
-    if crit is not None:
-        loss, _ = crit(out, y, w)
-    else:
-        loss = ((out - y) ** 2).mean()
-    loss.backward()
-    return loss
-
-
-class ConvTimer:
-    """Brackets every implicit-GEMM conv launch (forward and data-gradient) of the timed steps with
-    events on the launch stream.  The roofline entry is the dominant instantiation,
-    conv_igemm_kernel<bf16, NT=6, KS=3> (96-channel blocks, 3x3): 27 of the 36 launches per step."""
-
-    def __init__(self):
-        from unet_amd import ops
-        self.ops = ops
-        self.orig = ops.conv_fwd
-        self.records = []
-
-    def __enter__(self):
-        orig, records = self.orig, self.records
-
-        def timed(xin, pw, *a, **k):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = orig(xin, pw, *a, **k)
-            e1.record()
-            B, H, W_, _ = xin.shape
-            records.append((e0, e1, 2.0 * B * H * W_ * pw.Co * pw.Ci * pw.ks * pw.ks, pw.bn, pw.ks))
-            return r
-
-        self.ops.conv_fwd = timed
-        return self
-
-    def __exit__(self, *exc):
-        self.ops.conv_fwd = self.orig
-
-    def roofline(self, dt, steps):
-        peak = PEAK_BF16_TFLOPS if dt == torch.bfloat16 else PEAK_F32_TFLOPS
-        dom = [(e0.elapsed_time(e1), f) for e0, e1, f, bn, ks in self.records if bn == 96 and ks == 3]
-        fam = [(e0.elapsed_time(e1), f) for e0, e1, f, bn, ks in self.records]
-        ms, flops = sum(t for t, _ in dom), sum(f for _, f in dom)
-        fms, fflops = sum(t for t, _ in fam), sum(f for _, f in fam)
-        achieved = flops / (ms * 1e-3) / 1e12
-        tname = "bf16" if dt == torch.bfloat16 else "f32"
-        traffic = None
-        try:   # HBM bytes per launch of this kernel from separate rocprofv3 --pmc passes (tools/pmc_traffic.py)
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                traffic = json.load(f).get(f"conv_igemm_kernel<{tname},6,3>", {}).get("hbm_bytes_per_launch")
-        except (OSError, ValueError):
-            pass
-        return {"bound": "mfma", "kernel": f"conv_igemm_kernel<{tname},6,3> (forward + data-gradient launches)",
-                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                "traffic": traffic, "launches_per_step": len(dom) // steps,
-                "avg_launch_us": round(ms * 1e3 / len(dom), 2),
-                "algorithmic_gflop_per_launch": round(flops / len(dom) / 1e9, 2),
-                "conv_family": {"launches_per_step": len(fam) // steps,
-                                "ms_per_step": round(fms / steps, 3),
-                                "achieved": round(fflops / (fms * 1e-3) / 1e12, 2)}}
-
-
-def cpu_baseline(batch, size):
-    """The CPU oracle on a bounded sample: UNet(4,1,48) fwd + 'all' loss + bwd, batch `batch`."""
-    from oracle import loss_oracle, unet_oracle
-    from oracle import weights as W
-    threads = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(threads)
-    sd = W.fill_state_dict(W.unet_template(4, 1, 48), seed=42)
-    x, y, w = W.synthetic_batch(batch, 4, size, size, seed=42)
-    cfg = loss_oracle.preset("all")
-    times = []
-    for i in range(3):
-        t0 = time.perf_counter()
-        unet_oracle.unet_fwd_bwd(sd, x, lambda o: loss_oracle.multi_loss(cfg, o, y, w)[0])
-        times.append(time.perf_counter() - t0)
-    t = min(times[1:])
-    return {"value": round(batch / t, 3), "unit": "patches/s", "cores": threads, "kind": "port",
-            "sample": f"torch-CPU fp32 oracle, batch {batch} of 4x{size}x{size}, fwd+loss+bwd, best of 2 after 1 warm-up"}
-
-
-def barrier_sync(world):
-    torch.cuda.synchronize()
+# ---------------------------------------------------------------------------- timing helpers
+def barrier_sync(world, gpu=True):
+    if gpu:
+        torch.cuda.synchronize()
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
-        torch.cuda.synchronize()
+        if gpu:
+            torch.cuda.synchronize()
 
 
 def timed(fn, steps, warmup, world, dev):
-    """warmup untimed calls, then `steps` calls between barriers; max over ranks, seconds."""
+    """warmup untimed calls, then exactly `steps` calls between barriers; max over ranks, seconds."""
     for _ in range(warmup):
         fn()
     barrier_sync(world)
@@ -172,13 +137,305 @@ def timed(fn, steps, warmup, world, dev):
     return el
 
 
-def run_predict(args, rank, world, dev, dt):
-    """Tiled large-area inference (BASELINE config 4): UNet(4,1,48) eval over a synthetic grid,
-    256-px tiles with 50 % overlap, Gaussian blend; tile rows sharded over the ranks (strong scaling)."""
-    import numpy as np
+class ConvTimer:
+    """Brackets every implicit-GEMM launch that goes through ops.conv_fwd (3x3 convs forward and data
+    gradient, and the 1x1 / linear layers) with events on the launch stream."""
+
+    def __init__(self):
+        from unet_amd import ops
+        self.ops = ops
+        self.orig = ops.conv_fwd
+        self.records = []
+
+    def __enter__(self):
+        orig, records = self.orig, self.records
+
+        def timed_conv(xin, pw, *a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(xin, pw, *a, **k)
+            e1.record()
+            npix = xin.numel() // xin.shape[-1]
+            esz = xin.element_size()
+            records.append(dict(e0=e0, e1=e1, flops=2.0 * npix * pw.Co * pw.Ci * pw.ks * pw.ks, bn=pw.bn, ks=pw.ks,
+                                bytes=float(npix * (pw.Ci + pw.Co) * esz + pw.data.numel() * esz)))
+            return r
+
+        self.ops.conv_fwd = timed_conv
+        return self
+
+    def __exit__(self, *exc):
+        self.ops.conv_fwd = self.orig
+
+    def family(self, pred):
+        rows = [(r["e0"].elapsed_time(r["e1"]), r["flops"], r["bytes"]) for r in self.records if pred(r)]
+        ms = sum(t for t, _, _ in rows)
+        return len(rows), ms, sum(f for _, f, _ in rows), sum(b for _, _, b in rows)
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of a kernel from separate rocprofv3 --pmc passes (tools/pmc_traffic.py)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def mfma_roofline(timer, dt, steps, pred, kernel):
+    peak = PEAK_BF16_TFLOPS if dt == torch.bfloat16 else PEAK_F32_TFLOPS
+    n, ms, flops, _ = timer.family(pred)
+    if n == 0 or ms <= 0:
+        return None
+    achieved = flops / (ms * 1e-3) / 1e12
+    fn, fms, fflops, _ = timer.family(lambda r: r["ks"] == 3)
+    return {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": pmc_traffic(kernel.split(" ")[0]),
+            "launches_per_step": n // steps, "avg_launch_us": round(ms * 1e3 / n, 2),
+            "algorithmic_gflop_per_launch": round(flops / n / 1e9, 2),
+            "conv_family": {"launches_per_step": fn // steps, "ms_per_step": round(fms / steps, 3),
+                            "achieved": round(fflops / (fms * 1e-3) / 1e12, 2)} if fn else None}
+
+
+def host_threads():
+    """Threads for the CPU baseline: the cores this process may use (the box exports its share as
+    OMP_NUM_THREADS; os.cpu_count() would report the whole machine)."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    env = os.environ.get("OMP_NUM_THREADS")
+    if env and env.isdigit() and int(env) > 0:
+        avail = min(avail, int(env))
+    return max(1, avail)
+
+
+def median_time(fn, warmup=2, iters=5):
+    for _ in range(warmup):
+        fn()
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+# ---------------------------------------------------------------------------- UNet training step
+def run_train(args, rank, world, dev, dt):
     from oracle import weights as W
     from unet_amd import OptimizedUNet
-    from unet_amd.predictor import LargeAreaPredictor, LargeAreaPredictionConfig
+    from unet_amd.losses import MultiLossFunction
+    from unet_amd.optim import FusedAdamW
+    model = OptimizedUNet(4, 1, 48, compute_dtype=dt)
+    model.load_state_dict(W.fill_state_dict(W.unet_template(4, 1, 48), seed=42))
+    model = model.to(dev).train()
+    crit = MultiLossFunction(LOSS_CFG).to(dev)
+    x, y, w = W.synthetic_batch(args.batch, 4, args.size, args.size, seed=42 + rank)
+    x, y, w = x.to(dev), y.to(dev), w.to(dev)
+    reducer = None
+    if world > 1:
+        from unet_amd.dist import GradReducer
+        reducer = GradReducer(model)
+    # the trainer's optimizer tail (enhanced_training_multi_loss.py:758-763, 827-829)
+    opt = FusedAdamW(model.parameters(), lr=5e-5, weight_decay=5e-5, max_grad_norm=1.0)
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        loss, _ = crit(model(x), y, w)
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        opt.step()
+
+    for _ in range(args.warmup):
+        step()
+    timer = ConvTimer() if (rank == 0 and not args.no_roofline) else None
+    if timer is not None:
+        timer.__enter__()
+    el = timed(step, args.steps, 0, world, dev)
+    if timer is not None:
+        timer.__exit__()
+    ms = el / args.steps * 1e3
+    rec = None
+    if rank == 0:
+        tname = "bf16" if dt == torch.bfloat16 else "f32"
+        roof = None
+        if timer is not None:
+            roof = mfma_roofline(timer, dt, args.steps, lambda r: r["bn"] == 96 and r["ks"] == 3,
+                                 f"conv_igemm_kernel<{tname},6,3> (forward + data-gradient launches)")
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline_train(8, args.size)
+        rec = {
+            "metric": "train patches/s (fwd+bwd)", "value": round(world * args.batch * args.steps / el, 2),
+            "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"UNet(4,1,48) training step fwd+loss(all)+bwd+clip+AdamW, batch {args.batch}/GPU of "
+                                   f"4x{args.size}x{args.size}, {args.dtype} storage fp32 accumulate",
+                       "global_batch": world * args.batch, "patch": args.size,
+                       "parallelism": f"dp{world}" if world > 1 else "single"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+    if reducer is not None:
+        reducer.detach()
+    del model, opt, crit, x, y, w
+    torch.cuda.empty_cache()
+    return rec
+
+
+def cpu_baseline_train(batch, size):
+    """The CPU oracle on a bounded sample: UNet(4,1,48) fwd + 'all' loss + bwd, batch `batch`."""
+    from oracle import loss_oracle, unet_oracle
+    from oracle import weights as W
+    threads = host_threads()
+    torch.set_num_threads(threads)
+    sd = W.fill_state_dict(W.unet_template(4, 1, 48), seed=42)
+    x, y, w = W.synthetic_batch(batch, 4, size, size, seed=42)
+    cfg = loss_oracle.preset("all")
+    t = median_time(lambda: unet_oracle.unet_fwd_bwd(sd, x, lambda o: loss_oracle.multi_loss(cfg, o, y, w)[0]))
+    return {"value": round(batch / t, 3), "unit": "patches/s", "cores": threads, "kind": "port",
+            "sample": f"torch-CPU fp32 oracle, batch {batch} of 4x{size}x{size}, fwd+loss(all)+bwd, median of 5 after 2 "
+                      f"warm-ups, {threads} threads (host reports {os.cpu_count()} logical CPUs)"}
+
+
+# ---------------------------------------------------------------------------- Swin-UNet training step
+def run_swin(args, rank, world, dev, dt):
+    """BASELINE config 3 as swin_unet_model.py:809-823 runs it."""
+    from oracle import swin_oracle
+    from oracle import weights as W
+    from unet_amd import ops
+    from unet_amd.losses import MultiLossFunction
+    from unet_amd.optim import FusedAdamW
+    from unet_amd.swin import SwinUNet
+    cfg = dict(swin_oracle.DEFAULT_CONFIG)
+    model = SwinUNet(cfg, compute_dtype=dt)
+    model.load_state_dict(W.fill_state_dict(swin_oracle.swin_template(cfg), seed=42))
+    model = model.to(dev).train()
+    B = args.swin_batch
+    x, y, w = W.synthetic_batch(B, 4, args.size, args.size, seed=42 + rank)
+    x, y, w = x.to(dev), y.to(dev), w.to(dev)
+    crit = MultiLossFunction(SWIN_LOSS_CFG).to(dev)
+    reducer = None
+    if world > 1:
+        from unet_amd.dist import GradReducer
+        reducer = GradReducer(model)
+    opt = FusedAdamW(model.parameters(), lr=1e-4, weight_decay=0.05, max_grad_norm=1.0)
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        out = model(x)
+        if out.shape[-2:] != y.shape[-2:]:
+            out = ops.interpolate_bilinear(out, y.shape[-2:])
+        loss, _ = crit(out, y, w)
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        opt.step()
+
+    for _ in range(args.warmup):
+        step()
+    timer = LinearTimer() if (rank == 0 and not args.no_roofline) else None
+    if timer is not None:
+        timer.__enter__()
+    el = timed(step, args.steps, 0, world, dev)
+    if timer is not None:
+        timer.__exit__()
+    ms = el / args.steps * 1e3
+    rec = None
+    if rank == 0:
+        roof = timer.roofline(args.steps) if timer is not None else None
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline_swin(8, args.size)
+        rec = {
+            "metric": "train patches/s (fwd+bwd)", "value": round(world * B * args.steps / el, 2), "unit": "patches/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"SwinUNet (embed 96, depths 2-2-6-2, window 8) trainer step: fwd + bilinear x2 to the "
+                                   f"label + loss(tid_gradient) + bwd + clip + AdamW(1e-4, 0.05), batch {B}/GPU of "
+                                   f"4x{args.size}x{args.size}", "global_batch": world * B,
+                       "parallelism": f"dp{world}" if world > 1 else "single"},
+            "roofline": roof, "cpu_baseline": cpu}
+    if reducer is not None:
+        reducer.detach()
+    del model, opt, crit, x, y, w
+    torch.cuda.empty_cache()
+    return rec
+
+
+class LinearTimer:
+    """Events around the token-linear launches of the Swin encoder (forward and data gradient): the
+    dominant kernel family of the Swin step.  Priced against HBM: at 96..768 channels a token linear
+    moves (Ci + Co) x 2 bytes per token against 2 x Ci x Co FLOP, below the 312 FLOP/byte ridge on the
+    stage-0/1 layers that hold most of the tokens."""
+
+    def __init__(self):
+        from unet_amd import swin
+        self.swin = swin
+        self.records = []
+        self.orig = None
+
+    def __enter__(self):
+        self.orig = self.swin._linear_launch
+        orig, records = self.orig, self.records
+
+        def timed_linear(x, *a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(x, *a, **k)
+            e1.record()
+            out = r[0] if isinstance(r, tuple) else r
+            ntok = x.numel() // x.shape[-1]
+            ci, co = x.shape[-1], out.shape[-1]
+            records.append((e0, e1, 2.0 * ntok * ci * co, float((ntok * (ci + co) + ci * co) * x.element_size())))
+            return r
+
+        self.swin._linear_launch = timed_linear
+        return self
+
+    def __exit__(self, *exc):
+        self.swin._linear_launch = self.orig
+
+    def roofline(self, steps):
+        if not self.records:
+            return None
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in self.records)
+        flops = sum(f for _, _, f, _ in self.records)
+        byts = sum(b for _, _, _, b in self.records)
+        gbs = byts / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": "token-linear GEMM launches of the Swin encoder (forward + data gradient)",
+                "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                "traffic": None, "launches_per_step": len(self.records) // steps,
+                "ms_per_step": round(ms / steps, 3), "algorithmic_mb_per_step": round(byts / steps / 1e6, 1),
+                "mfma_tflops": round(flops / (ms * 1e-3) / 1e12, 1)}
+
+
+def cpu_baseline_swin(batch, size):
+    from oracle import loss_oracle, step_oracle, swin_oracle
+    from oracle import weights as W
+    threads = host_threads()
+    torch.set_num_threads(threads)
+    cfg = dict(swin_oracle.DEFAULT_CONFIG)
+    sd = W.fill_state_dict(swin_oracle.swin_template(cfg), seed=42)
+    x, y, w = W.synthetic_batch(batch, 4, size, size, seed=42)
+    lcfg = loss_oracle.preset("weighted_mse_grad", grad_w=0.3, spec_w=0.0)
+    t = median_time(lambda: step_oracle.swin_training_step(sd, x, y, w, cfg, lcfg), warmup=1, iters=3)
+    return {"value": round(batch / t, 3), "unit": "patches/s", "cores": threads, "kind": "port",
+            "sample": f"torch-CPU fp32 oracle of the trainer step, batch {batch} of 4x{size}x{size}, median of 3 after 1 "
+                      f"warm-up, {threads} threads"}
+
+
+# ---------------------------------------------------------------------------- tiled prediction
+def run_predict(args, rank, world, dev, dt):
+    """Tiled large-area inference (BASELINE config 4)."""
+    from oracle import weights as W
+    from unet_amd import OptimizedUNet
+    from unet_amd.predictor import LargeAreaPredictionConfig, LargeAreaPredictor
     model = OptimizedUNet(4, 1, 48, compute_dtype=dt)
     model.load_state_dict(W.fill_state_dict(W.unet_template(4, 1, 48), seed=42))
     model = model.to(dev).eval()
@@ -190,163 +447,160 @@ def run_predict(args, rank, world, dev, dt):
     g = torch.Generator(device="cpu").manual_seed(7)
     feats = torch.randn((4, args.grid, args.grid), generator=g).to(dev)
     pred = LargeAreaPredictor(Cfg)
+    steps, warmup = max(1, min(args.steps, 3)), max(1, min(args.warmup, 1))
     with torch.no_grad():
-        el = timed(lambda: pred.predict_device(model, feats), args.steps, args.warmup, world, dev)
-    ms = el / args.steps * 1e3
+        for _ in range(warmup):
+            pred.predict_device(model, feats)
+        timer = ConvTimer() if (rank == 0 and not args.no_roofline) else None
+        tiles = TileTimer(pred) if timer is not None else None
+        if timer is not None:
+            timer.__enter__()
+            tiles.__enter__()
+        el = timed(lambda: pred.predict_device(model, feats), steps, 0, world, dev)
+        if timer is not None:
+            tiles.__exit__()
+            timer.__exit__()
+    ms = el / steps * 1e3
     mpix = args.grid * args.grid / 1e6
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import tile_oracle, unet_oracle
-        torch.set_num_threads(min(os.cpu_count() or 1, 16))
-        sd = W.fill_state_dict(W.unet_template(4, 1, 48), seed=42)
-        n = 768
-        fs = {v: feats[i, :n, :n].cpu().numpy() for i, v in enumerate(tile_oracle.FEATURE_VARS)}
-        fn = lambda x: unet_oracle.unet_forward(sd, torch.from_numpy(x), training=False)[0].numpy()
-        t0 = time.perf_counter()
-        tile_oracle.predict_large_area(fn, fs, 256, 128, 16)
-        t = time.perf_counter() - t0
-        cpu = {"value": round(n * n / 1e6 / t, 4), "unit": "Mpix/s", "cores": torch.get_num_threads(), "kind": "port",
-               "sample": f"numpy/torch-CPU oracle on a {n}x{n} corner of the same grid (25 tiles)"}
+    rec = None
     if rank == 0:
+        tname = "bf16" if dt == torch.bfloat16 else "f32"
+        roof = None
+        if timer is not None:
+            roof = mfma_roofline(timer, dt, steps, lambda r: r["bn"] == 96 and r["ks"] == 3,
+                                 f"conv_igemm_kernel<{tname},6,3> (eval forward launches)")
+            if roof is not None:
+                roof["hbm_kernels"] = tiles.report(steps)
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline_predict(feats, min(2048, args.grid))
         ntile = ((args.grid - 256) // 128 + 1) ** 2
-        print(json.dumps({
+        rec = {
             "metric": "tiled-predict Mpix/s", "value": round(mpix / (ms * 1e-3), 2), "unit": "Mpix/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": f"LargeAreaPredictor over a {args.grid}x{args.grid} grid, 256-px tiles, stride 128 "
                                    f"({ntile} tiles), UNet(4,1,48) eval, Gaussian blend",
                        "parallelism": f"tile-row bands over {world} GPU(s)"},
-            "roofline": None, "cpu_baseline": cpu}), flush=True)
+            "roofline": roof, "cpu_baseline": cpu}
+    del model, feats, pred
+    torch.cuda.empty_cache()
+    return rec
 
 
-def run_swin(args, rank, world, dev, dt):
-    """Swin-UNet training step (BASELINE config 3): window 8, shifted windows, 256x256 input."""
-    from oracle import swin_oracle
+class TileTimer:
+    """Events around the tile gather and blend launches: achieved GB/s of algorithmic bytes against HBM."""
+
+    def __init__(self, predictor):
+        self.be = predictor.backend
+        self.rec = {"tile_gather": [], "blend_accumulate": []}
+
+    def __enter__(self):
+        be, rec = self.be, self.rec
+        self.orig = (be.gather, be.accumulate)
+        og, oa = self.orig
+
+        def gather(feats, pos_d, first, n, P, dt):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = og(feats, pos_d, first, n, P, dt)
+            e1.record()
+            rec["tile_gather"].append((e0, e1, float(n * P * P * (feats.shape[0] * 4 + r.shape[-1] * r.element_size()))))
+            return r
+
+        def accumulate(out, wk, slot, t0, t1, nti, ntj, P, S, acc, cnt, r0, r1):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            oa(out, wk, slot, t0, t1, nti, ntj, P, S, acc, cnt, r0, r1)
+            e1.record()
+            # per pixel of the rows touched: read+write acc and cnt; per tile pixel: read the prediction
+            rec["blend_accumulate"].append((e0, e1, float((r1 - r0) * acc.shape[1] * 16 + (t1 - t0) * P * P * 4)))
+
+        be.gather, be.accumulate = gather, accumulate
+        return self
+
+    def __exit__(self, *exc):
+        self.be.gather, self.be.accumulate = self.orig
+
+    def report(self, steps):
+        out = {}
+        for k, rows in self.rec.items():
+            if not rows:
+                continue
+            ms = sum(e0.elapsed_time(e1) for e0, e1, _ in rows)
+            byts = sum(b for _, _, b in rows)
+            gbs = byts / (ms * 1e-3) / 1e9
+            out[k] = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                      "ms_per_grid": round(ms / steps, 3), "launches_per_grid": len(rows) // steps}
+        return out
+
+
+def cpu_baseline_predict(feats, n):
+    import numpy as np
+    from oracle import tile_oracle, unet_oracle
     from oracle import weights as W
-    from unet_amd.swin import SwinUNet
-    cfg = dict(swin_oracle.DEFAULT_CONFIG)
-    model = SwinUNet(cfg, compute_dtype=dt)
-    model.load_state_dict(W.fill_state_dict(swin_oracle.swin_template(cfg), seed=42))
-    model = model.to(dev).train()
-    B = args.batch
-    x, _, _ = W.synthetic_batch(B, 4, args.size, args.size, seed=42 + rank)
-    x = x.to(dev)
-    tgt = torch.randn((B, 1, args.size // 2, args.size // 2), device=dev)
-    reducer = None
-    if world > 1:
-        from unet_amd.dist import GradReducer
-        reducer = GradReducer(model)
-
-    def step():
-        for p in model.parameters():
-            p.grad = None
-        loss = ((model(x) - tgt) ** 2).mean()
-        loss.backward()
-        if reducer is not None:
-            reducer.allreduce()
-
-    el = timed(step, args.steps, args.warmup, world, dev)
-    ms = el / args.steps * 1e3
-    if rank == 0:
-        print(json.dumps({
-            "metric": "train patches/s (fwd+bwd)", "value": round(world * B * args.steps / el, 2), "unit": "patches/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
-            "data": "synthetic",
-            "config": {"workload": f"SwinUNet (embed 96, depths 2-2-6-2, window 8) training step fwd+MSE+bwd, batch {B}/GPU "
-                                   f"of 4x{args.size}x{args.size}", "global_batch": world * B,
-                       "parallelism": f"dp{world}" if world > 1 else "single"},
-            "roofline": None, "cpu_baseline": None}), flush=True)
+    threads = host_threads()
+    torch.set_num_threads(threads)
+    sd = W.fill_state_dict(W.unet_template(4, 1, 48), seed=42)
+    fn = lambda x: unet_oracle.unet_forward(sd, torch.from_numpy(x), training=False)[0].numpy()
+    sub = lambda m: {v: np.ascontiguousarray(feats[i, :m, :m].cpu().numpy()) for i, v in enumerate(tile_oracle.FEATURE_VARS)}
+    tile_oracle.predict_large_area(fn, sub(512), 256, 128, 16)             # warm-up: 9 tiles
+    fs = sub(n)
+    t0 = time.perf_counter()
+    tile_oracle.predict_large_area(fn, fs, 256, 128, 16)
+    t = time.perf_counter() - t0
+    ntile = ((n - 256) // 128 + 1) ** 2
+    return {"value": round(n * n / 1e6 / t, 4), "unit": "Mpix/s", "cores": threads, "kind": "port",
+            "sample": f"numpy/torch-CPU oracle on the {n}x{n} corner of the same grid ({ntile} tiles), one timed pass "
+                      f"after a 512x512 warm-up, {threads} threads"}
 
 
+# ---------------------------------------------------------------------------- main
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if os.environ.get("UNETK_BENCH_DRYRUN"):
+        # launcher rehearsal without GPUs: rendezvous over gloo, one reduction, the one JSON line
+        import torch.distributed as dist
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)])
+        if world > 1:
+            dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"metric": "train patches/s (fwd+bwd)", "value": 0.0, "n_gpus": world, "dry_run": True,
+                              "rank_sum": t.item()}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
-    from oracle import weights as W
-    from unet_amd import OptimizedUNet
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    if args.workload != "train":
-        (run_predict if args.workload == "predict" else run_swin)(args, rank, world, dev, dt)
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
-    model = OptimizedUNet(4, 1, 48, compute_dtype=dt)
-    model.load_state_dict(W.fill_state_dict(W.unet_template(4, 1, 48), seed=42))
-    model = model.to(dev).train()
-    crit, loss_name = make_loss()
-    if crit is not None:
-        crit = crit.to(dev)
-    x, y, w = W.synthetic_batch(args.batch, 4, args.size, args.size, seed=42 + rank)
-    x, y, w = x.to(dev), y.to(dev), w.to(dev)
-
-    reducer = None
-    if world > 1:
-        from unet_amd.dist import GradReducer
-        reducer = GradReducer(model)
-    # the trainer's optimizer tail (enhanced_training_multi_loss.py:758-763, 827-829)
-    from unet_amd.optim import FusedAdamW
-    opt = FusedAdamW(model.parameters(), lr=5e-5, weight_decay=5e-5, max_grad_norm=1.0)
-
-    def step():
-        loss = train_step(model, crit, x, y, w)
-        if reducer is not None:
-            reducer.allreduce()
-        opt.step()
-        return loss
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    timer = ConvTimer() if (rank == 0 and not args.no_roofline) else None
-    if timer is not None:
-        timer.__enter__()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if timer is not None:
-        timer.__exit__()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = t.item()
-    ms = el / args.steps * 1e3
-    value = world * args.batch * args.steps / el
-
-    roof = None
-    cpu = None
+    runners = {"train": run_train, "swin": run_swin, "predict": run_predict}
+    if args.workload != "all":
+        line = runners[args.workload](args, rank, world, dev, dt)
+    else:
+        line = run_train(args, rank, world, dev, dt)
+        extra = {}
+        for name in ("swin", "predict"):
+            try:
+                extra[name] = runners[name](args, rank, world, dev, dt)
+            except Exception as e:      # the headline line must still come out; the failure is recorded in it
+                extra[name] = {"error": f"{type(e).__name__}: {e}"}
+                if world > 1:
+                    raise
+        if rank == 0:
+            line.update(extra)
     if rank == 0:
-        if timer is not None:
-            roof = timer.roofline(dt, args.steps)
-        if not args.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline(4, args.size)
-        line = {
-            "metric": "train patches/s (fwd+bwd)", "value": round(value, 2), "unit": "patches/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"UNet(4,1,48) training step fwd+loss({loss_name})+bwd+clip+AdamW, batch {args.batch}/GPU of "
-                                   f"4x{args.size}x{args.size}, {args.dtype} storage fp32 accumulate",
-                       "global_batch": world * args.batch, "patch": args.size,
-                       "parallelism": f"dp{world}" if world > 1 else "single"},
-            "roofline": roof, "cpu_baseline": cpu,
-        }
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -135,6 +135,13 @@ int unetk_upsample_concat_fwd(const void* low, int h, int w, int C1, const void*
 int unetk_upsample_bwd(const void* dout, int ldout, int H, int W, void* dlow, int B, int h, int w, int C1,
                        int dtype, unetk_stream_t stream);
 
+/* F.interpolate(outputs, size=labels.shape[-2:], mode='bilinear', align_corners=False) on the fp32
+ * NCHW prediction before the loss (swin_unet_model.py:812-814): in (planes,h,w) -> out (planes,H,W),
+ * planes = B*C.  backward=1: in is the gradient of the (planes,H,W) result and out receives the
+ * gradient of the (planes,h,w) source (gather form, deterministic). */
+int unetk_resize_planes_f32(const float* in, float* out, int64_t planes, int h, int w, int H, int W, int backward,
+                            unetk_stream_t stream);
+
 /* ---- final nn.Conv2d(C, Co, 1) with bias, NHWC in -> NCHW fp32 out --------------------
  * training.py:482,520; swin_unet_model.py:611 */
 int unetk_head1x1_fwd(const void* x, int ldx, const float* w, const float* bias, float* out, int B, int H,
@@ -155,6 +162,17 @@ int unetk_loss_spectral_blocks(int H, int W);
 int unetk_loss_pixgrad_fwd(const float* pred, const float* target, const float* w, int B, int H, int W,
                            int pixel_mae, int grad_method, int pixel_use_w, float tid_scale, float* gx,
                            float* gy, float* partials, float* res, unetk_stream_t stream);
+/* unetk_loss_pixgrad_fwd for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc): the partial sums live in a 45 KB
+ * device array inside the library, one copy per GPU, whose address is looked up once per device.
+ * This entry point has no counterpart in the reference.  It allocates nothing and gives the same
+ * bits as unetk_loss_pixgrad_fwd.  B*H*W may be at most unetk_loss_static_max_pixels() (2^30);
+ * larger inputs are refused with UNETK_EINVAL.  All calls on one GPU share that GPU's array:
+ * calls that overlap on one GPU (different streams) race; calls on one stream are ordered. */
+int64_t unetk_loss_static_max_pixels(void);
+int unetk_loss_pixgrad_fwd_static(const float* pred, const float* target, const float* w, int B, int H, int W,
+                                  int pixel_mae, int grad_method, int pixel_use_w, float tid_scale, float* gx,
+                                  float* gy, float* res, unetk_stream_t stream);
 /* Fp, Ft: complex64 fft2 of pred / target (B,H,W); partials, wsum: [B][spectral_blocks]; coef: [B] */
 int unetk_loss_spectral_fwd(const void* Fp, const void* Ft, const float* w, int B, int H, int W, float factor,
                             float* partials, float* wsum, float* coef, float* res, unetk_stream_t stream);

@@ -9,7 +9,9 @@ from typing import Dict, Tuple
 
 import torch
 
-from . import loss_oracle, unet_oracle
+import torch.nn.functional as F
+
+from . import loss_oracle, swin_oracle, unet_oracle
 
 
 def clip_coefficient(grads: Dict[str, torch.Tensor], max_norm: float) -> Tuple[float, float]:
@@ -49,3 +51,27 @@ def training_step(sd, x, y, w, loss_cfg, lr=5e-5, weight_decay=5e-5, max_norm=1.
         new[k], _, _ = adamw_update(sd[k], g, torch.zeros_like(g), torch.zeros_like(g), 1, lr,
                                     weight_decay=weight_decay)
     return parts_box, norm, new
+
+
+def swin_training_step(sd, x, y, w, cfg, loss_cfg, lr=1e-4, weight_decay=0.05, max_norm=1.0):
+    """First step of the Swin trainer (swin_unet_model.py:809-823; AdamW at :759-763 with the config's
+    LEARNING_RATE 1e-4 and WEIGHT_DECAY 0.05, :730-731): forward, bilinear resize of the half-resolution
+    output to the label size, multi-loss, backward, clip_grad_norm_(1.0), AdamW.  DropPath off.
+    Returns (loss parts, grad norm, new params, grads)."""
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()
+              if v.is_floating_point() and "running_" not in k}
+    full = dict(sd)
+    full.update(params)
+    out, _ = swin_oracle.swin_unet_forward(full, x, cfg, True, None)
+    if out.shape[-2:] != y.shape[-2:]:
+        out = F.interpolate(out, size=y.shape[-2:], mode="bilinear", align_corners=False)
+    total, parts = loss_oracle.multi_loss(loss_cfg, out, y, w)
+    total.backward()
+    grads = {k: p.grad for k, p in params.items()}
+    norm, coef = clip_coefficient(grads, max_norm)
+    new = {}
+    for k, g in grads.items():
+        g = g * coef if coef < 1.0 else g
+        new[k], _, _ = adamw_update(sd[k], g, torch.zeros_like(g), torch.zeros_like(g), 1, lr,
+                                    weight_decay=weight_decay)
+    return parts, norm, new, grads

@@ -42,7 +42,34 @@ def _r(t):
     return t + (t.to(torch.bfloat16).to(t.dtype) - t).detach()
 
 
-def _double_conv_bf16(sd, name, x, training, mask, new_stats):
+class _RoundGrad(torch.autograd.Function):
+    """Identity whose gradient is rounded to bfloat16 storage: models a gradient tensor kept in bf16."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+BF16_DEFAULT = frozenset({"w", "y", "a"})
+BF16_ALL = frozenset({"w", "y", "a", "dy", "da"})
+
+
+def _classes(emulate_bf16):
+    """emulate_bf16: False, True (weights, raw conv outputs and activations are rounded) or a set of the
+    stored-tensor classes to round: 'w' packed weights, 'y' raw conv output, 'a' activation (and the
+    network input and resized tensors), 'dy' gradient of the conv output, 'da' gradient of the activation."""
+    if not emulate_bf16:
+        return frozenset()
+    if emulate_bf16 is True:
+        return BF16_DEFAULT
+    return frozenset(emulate_bf16)
+
+
+def _double_conv_bf16(sd, name, x, training, mask, new_stats, classes=BF16_DEFAULT):
     """_double_conv with the roundings a bfloat16-storage pipeline performs.
 
     Conv operands (activations, weights) and every stored activation are rounded to bf16;
@@ -53,7 +80,10 @@ def _double_conv_bf16(sd, name, x, training, mask, new_stats):
     distance from the fp32 model is the price of bf16 storage, not of the kernels.
     """
     for unit, (conv_i, bn_i) in enumerate(((0, 1), (3, 4))):
-        y32 = F.conv2d(x, _r(sd[f"{name}.{conv_i}.weight"]), None, padding=1)
+        wgt = sd[f"{name}.{conv_i}.weight"]
+        y32 = F.conv2d(x, _r(wgt) if "w" in classes else wgt, None, padding=1)
+        if "dy" in classes:
+            y32 = _RoundGrad.apply(y32)
         g, b = sd[f"{name}.{bn_i}.weight"], sd[f"{name}.{bn_i}.bias"]
         if training:
             mean = y32.mean((0, 2, 3))
@@ -64,7 +94,7 @@ def _double_conv_bf16(sd, name, x, training, mask, new_stats):
             new_stats[f"{name}.{bn_i}.running_var"] = (
                 (1 - BN_MOMENTUM) * sd[f"{name}.{bn_i}.running_var"]
                 + BN_MOMENTUM * var.detach() * (n / max(n - 1, 1)))
-            y = _r(y32)
+            y = _r(y32) if "y" in classes else y32
         else:
             mean, var = sd[f"{name}.{bn_i}.running_mean"], sd[f"{name}.{bn_i}.running_var"]
             y = y32
@@ -73,7 +103,10 @@ def _double_conv_bf16(sd, name, x, training, mask, new_stats):
         x = F.relu(y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
         if unit == 1 and training and mask is not None:   # the mask is applied before the single rounding
             x = x * mask.view(mask.shape[0], mask.shape[1], 1, 1)
-        x = _r(x)
+        if "a" in classes:
+            x = _r(x)
+        if "da" in classes:
+            x = _RoundGrad.apply(x)
     return x
 
 
@@ -105,8 +138,12 @@ def unet_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, training: bool = 
     """
     new_stats: Dict[str, torch.Tensor] = {}
     m = dropout_masks if dropout_masks is not None else [None] * 9
-    block = _double_conv_bf16 if emulate_bf16 else _double_conv
-    rnd = _r if emulate_bf16 else (lambda t: t)
+    classes = _classes(emulate_bf16)
+    if classes:
+        block = lambda *a: _double_conv_bf16(*a, classes=classes)
+    else:
+        block = _double_conv
+    rnd = _r if "a" in classes else (lambda t: t)
     x = rnd(x)
     e1 = block(sd, "encoder1", x, training, m[0], new_stats)
     e2 = block(sd, "encoder2", F.max_pool2d(e1, 2, 2), training, m[1], new_stats)

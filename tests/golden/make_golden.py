@@ -26,7 +26,7 @@ REF = "/root/reference"
 sys.path.insert(0, REPO)
 sys.dont_write_bytecode = True
 
-from oracle import filter_oracle, loss_oracle, patch_oracle, swin_oracle, tile_oracle, unet_oracle  # noqa: E402
+from oracle import filter_oracle, loss_oracle, patch_oracle, step_oracle, swin_oracle, tile_oracle, unet_oracle  # noqa: E402
 from oracle import weights as W  # noqa: E402
 
 
@@ -348,6 +348,211 @@ def gen_swin(swin):
     np.savez_compressed(os.path.join(HERE, "swin.npz"), **out)
     print("swin.npz", len(out), "entries")
 
+def _flat(gs, names):
+    return torch.cat([gs[n].double().reshape(-1) for n in names])
+
+
+def _rel(a, b):
+    a, b = torch.as_tensor(a).double().reshape(-1), torch.as_tensor(b).double().reshape(-1)
+    return float((a - b).norm() / b.norm().clamp_min(1e-300))
+
+
+def _cos(a, b):
+    a, b = torch.as_tensor(a).double().reshape(-1), torch.as_tensor(b).double().reshape(-1)
+    return float(torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-300))
+
+
+def _ref_train_pass(model, x, loss_of, autocast):
+    """One train-mode forward + backward of a reference module, optionally under CPU bf16 autocast.
+    Returns (output fp32, loss, {name: grad}, input grad)."""
+    import contextlib
+    model.zero_grad()
+    xin = x.clone().requires_grad_(True)
+    ctx = torch.autocast("cpu", dtype=torch.bfloat16) if autocast else contextlib.nullcontext()
+    with ctx:
+        out = model(xin)
+    out32 = out.float()
+    loss = loss_of(out32)
+    loss.backward()
+    return out32.detach(), float(loss), {k: p.grad.detach().clone() for k, p in model.named_parameters()}, \
+        xin.grad.detach().clone()
+
+
+def _bf16_record(out, prefix, model, x, loss_of):
+    """Distance of the reference's own bf16-autocast run from its fp32 run on one case."""
+    o32, l32, g32, dx32 = _ref_train_pass(model, x, loss_of, False)
+    o16, l16, g16, dx16 = _ref_train_pass(model, x, loss_of, True)
+    names = [k for k, _ in model.named_parameters()]
+    a, b = _flat(g16, names), _flat(g32, names)
+    # parameters whose gradient is pure rounding noise (a conv bias in front of BatchNorm) carry no signal
+    floor = 1e-6 * float(b.norm())
+    per = [(_rel(g16[k], g32[k]) if float(g32[k].double().norm()) > floor else 0.0) for k in names]
+    rec = dict(out_rel=_rel(o16, o32), loss_rel=abs(l16 - l32) / abs(l32), grad_rel=_rel(a, b), grad_cos=_cos(a, b),
+               dx_rel=_rel(dx16, dx32), dx_cos=_cos(dx16, dx32), grad_rel_worst=max(per))
+    for k, v in rec.items():
+        out[f"{prefix}.{k}"] = np.float64(v)
+    out[f"{prefix}.param_names"] = np.array(names)
+    out[f"{prefix}.grad_rel_per_param"] = np.array(per)
+    print(prefix, {k: round(v, 4) for k, v in rec.items()})
+
+
+def gen_bf16(tr, swin):
+    """What bfloat16 costs the REFERENCE: its modules run train-mode forward + backward under
+    torch.autocast('cpu', dtype=torch.bfloat16) and are compared with their own fp32 run on the same
+    seeded cases as unet.npz / swin.npz.  These numbers bound the bf16 GPU path (no worse than 1.3x)."""
+    out = {}
+    for name, cin, f, B, H, Wd in UNET_CASES:
+        sd = W.fill_state_dict(W.unet_template(cin, 1, f), seed=42)
+        x, y, w = W.synthetic_batch(B, cin, H, Wd, seed=42)
+        ref = tr.OptimizedUNet(cin, 1, f)
+        ref.load_state_dict(sd)
+        ref.train()
+        for m in ref.modules():
+            if isinstance(m, torch.nn.Dropout2d):
+                m.p = 0.0
+        _bf16_record(out, f"unet.{name}", ref, x, lambda o, y=y: ((o - y) ** 2).mean())
+        # eval forward under autocast against fp32 eval
+        ref.eval()
+        with torch.no_grad():
+            e32 = ref(x)
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                e16 = ref(x).float()
+        out[f"unet.{name}.eval_rel"] = np.float64(_rel(e16, e32))
+    cfg = dict(swin_oracle.DEFAULT_CONFIG)
+    ref = swin.SwinUNet(dict(cfg, use_checkpoint=False))
+    sd = W.fill_state_dict({k: v for k, v in ref.state_dict().items()}, seed=42)
+    for name, B, H, Wd in SWIN_BF16_CASES:
+        x, y, w = W.synthetic_batch(B, 4, H, Wd, seed=42)
+        ref.load_state_dict(sd)
+        ref.train()
+        for m in ref.modules():
+            if isinstance(m, swin.DropPath):
+                m.drop_prob = 0.0
+        tgt = torch.nn.functional.avg_pool2d(y, 2)
+        _bf16_record(out, f"swin.{name}", ref, x, lambda o, tgt=tgt: ((o - tgt) ** 2).mean())
+        ref.eval()
+        with torch.no_grad():
+            e32 = ref(x)
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                e16 = ref(x).float()
+        out[f"swin.{name}.eval_rel"] = np.float64(_rel(e16, e32))
+    np.savez_compressed(os.path.join(HERE, "bf16.npz"), **out)
+    print("bf16.npz", len(out), "entries")
+
+
+SWIN_BF16_CASES = [("s64", 2, 64, 64), ("s128x64", 1, 128, 64), ("s256", 1, 256, 256)]
+
+SWIN2_CASES = [("s256", 1, 256, 256), ("s24", 2, 24, 24)]
+
+
+def gen_swin2(swin):
+    """Two more Swin cases, train mode in float64 as in gen_swin: the full-size no-pad path (256 px:
+    64/32/16/8 tokens a side, 64/16/4/1 windows) and a 24-px input, whose 6x6 / 3x3 / 2x2 / 1x1 token
+    grids take the padded-window path in every stage, the odd-size PatchMerging pad, and the decoder's
+    bilinear resize of the projected skip (swin_unet_model.py:526-529: 3x3 -> 4x4 and 6x6 -> 8x8)."""
+    out = {}
+    cfg = dict(swin_oracle.DEFAULT_CONFIG)
+    ref32 = swin.SwinUNet(dict(cfg, use_checkpoint=False))
+    sd = W.fill_state_dict({k: v for k, v in ref32.state_dict().items()}, seed=42)
+    ref32.load_state_dict(sd)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    for name, B, H, Wd in SWIN2_CASES:
+        x, y, w = W.synthetic_batch(B, 4, H, Wd, seed=42)
+        if name != "s256":       # s256.eval_out is in swin.npz already
+            ref32.eval()
+            with torch.no_grad():
+                r_eval = ref32(x)
+            o_eval, _ = swin_oracle.swin_unet_forward(sd, x, cfg, False)
+            close(o_eval, r_eval, 1e-5, f"swin {name} eval")
+            out[f"{name}.eval_out"] = sub(r_eval, 16384)
+        ref64 = swin.SwinUNet(dict(cfg, use_checkpoint=False)).double()
+        ref64.load_state_dict(sd64)
+        ref64.train()
+        for m in ref64.modules():
+            if isinstance(m, swin.DropPath):
+                m.drop_prob = 0.0
+        x64 = x.double()
+        xr_ = x64.clone().requires_grad_(True)
+        r_out = ref64(xr_)
+        # the reference trainer resizes the prediction to the label's size (:812-814); here the label is
+        # resized to the prediction instead so that only the model is under test
+        tgt = torch.nn.functional.interpolate(y.double(), size=r_out.shape[-2:], mode="bilinear", align_corners=False)
+        r_loss = ((r_out - tgt) ** 2).mean()
+        r_loss.backward()
+        params = {k: v.clone().requires_grad_(True) for k, v in sd64.items()
+                  if v.is_floating_point() and "running_" not in k}
+        full = dict(sd64)
+        full.update(params)
+        xo = x64.clone().requires_grad_(True)
+        o_out, o_stats = swin_oracle.swin_unet_forward(full, xo, cfg, True, None)
+        ((o_out - tgt) ** 2).mean().backward()
+        close(o_out, r_out, 1e-12, f"swin {name} train out")
+        rsd = ref64.state_dict()
+        for k, p in ref64.named_parameters():
+            if k == "final_conv.0.bias":
+                continue
+            close(params[k].grad, p.grad, 1e-9, f"swin {name} grad {k}")
+        close(xo.grad, xr_.grad, 1e-9, f"swin {name} grad input")
+        for k, v in o_stats.items():
+            close(v, rsd[k], 1e-12, f"swin {name} stat {k}")
+        out[f"{name}.out_shape"] = np.array(r_out.shape)
+        out[f"{name}.train_out"] = sub(r_out, 16384)
+        out[f"{name}.loss"] = np.float64(r_loss.item())
+        out[f"{name}.grad_norms"] = np.array([p.grad.norm().item() for _, p in ref64.named_parameters()])
+        out[f"{name}.param_names"] = np.array([k for k, _ in ref64.named_parameters()])
+        out[f"{name}.grad_input"] = sub(xr_.grad, 4096)
+        stat_names = sorted(o_stats)
+        out[f"{name}.stat_names"] = np.array(stat_names)
+        out[f"{name}.stats"] = np.concatenate([sub(rsd[k], 8) for k in stat_names])
+    np.savez_compressed(os.path.join(HERE, "swin2.npz"), **out)
+    print("swin2.npz", len(out), "entries")
+
+
+SWIN_STEP_LOSS = dict(comb="weighted_mse_grad", grad_w=0.3, spec_w=0.0)      # SWIN_LOSS_CONFIGS['tid_gradient']
+
+
+def gen_step_swin(swin, etml):
+    """One optimiser step as the Swin trainer does it (swin_unet_model.py:809-823): model, bilinear resize of
+    the half-resolution prediction to the label size, MultiLossFunction('tid_gradient'), zero_grad, backward,
+    clip_grad_norm_(1.0), AdamW(lr 1e-4, weight decay 0.05).  DropPath off."""
+    cfg = dict(swin_oracle.DEFAULT_CONFIG)
+    B, H, Wd = 2, 64, 64
+    ref = swin.SwinUNet(dict(cfg, use_checkpoint=False))
+    sd = W.fill_state_dict({k: v for k, v in ref.state_dict().items()}, seed=42)
+    ref.load_state_dict(sd)
+    ref.train()
+    for m in ref.modules():
+        if isinstance(m, swin.DropPath):
+            m.drop_prob = 0.0
+    x, y, w = W.synthetic_batch(B, 4, H, Wd, seed=42)
+    lcfg = loss_oracle.preset(**SWIN_STEP_LOSS)
+    assert {k: lcfg[k] for k in lcfg} == {k: swin.SWIN_LOSS_CONFIGS["tid_gradient"][k] for k in lcfg}
+    crit = etml.MultiLossFunction(lcfg)
+    opt = torch.optim.AdamW(ref.parameters(), lr=1e-4, weight_decay=0.05)
+    outputs = ref(x)
+    assert outputs.shape[-2:] == (H // 2, Wd // 2)
+    outputs = torch.nn.functional.interpolate(outputs, size=y.shape[-2:], mode="bilinear", align_corners=False)
+    loss, parts = crit(outputs, y, w)
+    opt.zero_grad()
+    loss.backward()
+    grads = {k: p.grad.detach().clone() for k, p in ref.named_parameters()}
+    gn = torch.nn.utils.clip_grad_norm_(ref.parameters(), max_norm=1.0)
+    opt.step()
+    o_parts, o_norm, o_new, o_grads = step_oracle.swin_training_step(sd, x, y, w, cfg, lcfg)
+    for k in ("pixel", "gradient", "spectral", "total"):
+        assert abs(o_parts[k] - parts[k]) <= 1e-5 * max(1.0, abs(parts[k])), (k, o_parts, parts)
+    assert abs(o_norm - gn.item()) <= 1e-3 * gn.item(), (o_norm, gn.item())
+    names = [k for k, _ in ref.named_parameters()]
+    out = {"parts": np.array([parts[k] for k in ("pixel", "gradient", "spectral", "total")]),
+           "grad_norm": np.float64(gn.item()),
+           "param_names": np.array(names),
+           "grad_norms": np.array([grads[k].double().norm().item() for k in names]),
+           "param_delta_norms": np.array([(p.detach() - sd[k]).double().norm().item()
+                                          for k, p in ref.named_parameters()]),
+           "param_heads": np.concatenate([sub(p, 8) for _, p in ref.named_parameters()])}
+    np.savez_compressed(os.path.join(HERE, "step_swin.npz"), **out)
+    print("step_swin.npz", len(out), "entries; grad norm", gn.item(), parts)
+
 
 def gen_step(etml):
     """One optimiser step as the trainer does it (enhanced_training_multi_loss.py:819-829)."""
@@ -450,7 +655,7 @@ def gen_filter():
 if __name__ == "__main__":
     torch.set_num_threads(8)
     tr, etml, swin, lap = import_reference()
-    which = sys.argv[1:] or ["unet", "loss", "tile", "swin", "step", "patch", "filter"]
+    which = sys.argv[1:] or ["unet", "loss", "tile", "swin", "step", "patch", "filter", "bf16", "swin2", "step_swin"]
     if "unet" in which:
         gen_unet(tr)
     if "loss" in which:
@@ -461,6 +666,12 @@ if __name__ == "__main__":
         gen_swin(swin)
     if "step" in which:
         gen_step(etml)
+    if "bf16" in which:
+        gen_bf16(tr, swin)
+    if "swin2" in which:
+        gen_swin2(swin)
+    if "step_swin" in which:
+        gen_step_swin(swin, etml)
     if "patch" in which:
         gen_patch(etml)
     if "filter" in which:

@@ -84,36 +84,163 @@ def _reduce_worker(rank, world, port, q):
     m = torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.Linear(53, 11))
     broadcast_parameters(m)
     g = torch.Generator().manual_seed(100 + rank)
-    for p in m.parameters():
-        p.grad = torch.randn(p.shape, generator=g)
     red = GradReducer(m, bucket_bytes=4096)      # several buckets
     assert len(red.buckets) > 1
+    for p in m.parameters():                     # gradients set by hand: nothing was launched during a backward
+        p.grad = torch.randn(p.shape, generator=g)
     red.allreduce()
     if rank == 0:
-        q.put(([p.grad.clone() for p in m.parameters()], [p.detach().clone() for p in m.parameters()]))
+        # numpy arrays travel by value (tensors travel as file descriptors of a process that may be gone)
+        q.put(([p.grad.numpy().copy() for p in m.parameters()], [p.detach().numpy().copy() for p in m.parameters()]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_grad_reducer_averages_per_shard_gradients():
-    world = 2
+def _spawn(target, world, port, *args):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_reduce_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=target, args=(r, world, port) + args + (q,)) for r in range(world)]
     for p in procs:
         p.start()
-    grads, params = q.get(timeout=120)
+    out = q.get(timeout=180)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    return out
+
+
+def test_grad_reducer_averages_per_shard_gradients():
+    world = 2
+    grads, params = _spawn(_reduce_worker, world, 31500 + os.getpid() % 2000)
     torch.manual_seed(0)
     m = torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.Linear(53, 11))
     for a, b in zip(params, m.parameters()):
-        assert torch.equal(a, b.detach())           # broadcast from rank 0
+        assert torch.equal(torch.from_numpy(a), b.detach())           # broadcast from rank 0
     shapes = [p.shape for p in m.parameters()]
     gens = [torch.Generator().manual_seed(100 + r) for r in range(world)]
     per_rank = [[torch.randn(s, generator=g) for s in shapes] for g in gens]
     for i in range(len(shapes)):
         want = (per_rank[0][i] + per_rank[1][i]) / world
-        assert torch.allclose(grads[i], want, rtol=1e-6, atol=1e-7)
+        assert torch.allclose(torch.from_numpy(grads[i]), want, rtol=1e-6, atol=1e-7)
+
+
+class _StandIn(torch.nn.Module):
+    """BatchNorm-bearing stand-in with the UNet's ingredients (conv, batch-statistic BatchNorm, ReLU, pooling,
+    a skip concat) small enough for the CPU; plain torch autograd, so gradients reach the reducer through
+    its per-parameter hooks while the backward pass is still running."""
+
+    def __init__(self):
+        super().__init__()
+        nn = torch.nn
+        self.enc = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1, bias=False), nn.BatchNorm2d(8), nn.ReLU())
+        self.mid = nn.Sequential(nn.Conv2d(8, 16, 3, padding=1, bias=False), nn.BatchNorm2d(16), nn.ReLU())
+        self.dec = nn.Sequential(nn.Conv2d(24, 8, 3, padding=1, bias=False), nn.BatchNorm2d(8), nn.ReLU())
+        self.head = nn.Conv2d(8, 1, 1)
+
+    def forward(self, x):
+        e = self.enc(x)
+        m = self.mid(torch.nn.functional.max_pool2d(e, 2))
+        u = torch.nn.functional.interpolate(m, size=e.shape[-2:], mode="bilinear", align_corners=False)
+        return self.head(self.dec(torch.cat((u, e), 1)))
+
+
+def _standin_data(rank):
+    g = torch.Generator().manual_seed(500 + rank)
+    x = torch.randn((3, 3, 12, 10), generator=g) * (1.0 + rank)        # shards with different statistics
+    y = torch.randn((3, 1, 12, 10), generator=g)
+    w = (torch.rand((3, 1, 12, 10), generator=g) > 0.3 + 0.2 * rank).float()   # count(w > 0) differs per shard
+    return x, y, w
+
+
+def _shard_step(m, rank):
+    from oracle import loss_oracle
+    x, y, w = _standin_data(rank)
+    loss, _ = loss_oracle.multi_loss(loss_oracle.preset("weighted_mse_grad"), m(x), y, w)
+    loss.backward()
+
+
+def _dp_contract_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from unet_amd.dist import GradReducer, broadcast_parameters
+    torch.manual_seed(1234 + rank)
+    m = _StandIn().train()
+    broadcast_parameters(m)
+    red = GradReducer(m, bucket_bytes=2048)
+    assert len(red.buckets) > 2
+    launched = []
+    for step in range(2):                       # the buckets are persistent: a second step re-uses them
+        m.zero_grad(set_to_none=True)
+        _shard_step(m, rank)
+        launched.append(sum(b.work is not None for b in red.buckets))      # collectives started inside backward
+        red.finish()
+    out = ([p.grad.numpy().copy() for p in m.parameters()],
+           {k: v.numpy().copy() for k, v in m.state_dict().items() if "running" in k}, launched)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, out)
+    if rank == 0:
+        q.put(gathered)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_dp_step_equals_mean_of_per_shard_reference_gradients(world):
+    """The data-parallel contract on a BatchNorm-bearing model: after an N-rank step every rank holds the MEAN
+    of the N per-shard single-process gradients; BatchNorm statistics and the weighted-loss normalisation stay
+    per shard (so this differs from one big-batch step)."""
+    gathered = _spawn(_dp_contract_worker, world, 33500 + (os.getpid() + world) % 2000)
+    # single-process references: the same initial weights (rank 0's), each shard alone, two steps
+    torch.manual_seed(1234)
+    init = _StandIn().state_dict()
+    per_shard, stats = [], []
+    for r in range(world):
+        m = _StandIn().train()
+        m.load_state_dict(init)
+        for step in range(2):
+            m.zero_grad(set_to_none=True)
+            _shard_step(m, r)
+        per_shard.append([p.grad.clone() for p in m.parameters()])
+        stats.append({k: v.clone() for k, v in m.state_dict().items() if "running" in k})
+    want = [sum(gs) / world for gs in zip(*per_shard)]
+    for r, (grads, run, launched) in enumerate(gathered):
+        for a, b in zip(grads, want):
+            assert torch.allclose(torch.from_numpy(a), b, rtol=1e-5, atol=1e-7), r
+        for k in stats[r]:
+            assert torch.equal(torch.from_numpy(run[k]), stats[r][k]), (r, k)       # un-synced BatchNorm: every rank keeps its own
+        assert all(n >= len(want) // 4 for n in launched), launched   # most buckets went out during backward
+    # and it is NOT the big-batch gradient (BatchNorm couples the samples of a batch)
+    m = _StandIn().train()
+    m.load_state_dict(init)
+    from oracle import loss_oracle
+    xs, ys, ws = zip(*[_standin_data(r) for r in range(world)])
+    for step in range(2):
+        m.zero_grad(set_to_none=True)
+        loss, _ = loss_oracle.multi_loss(loss_oracle.preset("weighted_mse_grad"), m(torch.cat(xs)), torch.cat(ys),
+                                         torch.cat(ws))
+        loss.backward()
+    big = [p.grad for p in m.parameters()]
+    assert any(not torch.allclose(a, b, rtol=1e-3, atol=1e-6) for a, b in zip(big, want))
+
+
+def test_bench_launcher_starts_ranks_and_prints_one_line():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset starts two rank processes itself (rehearsed on the CPU:
+    gloo rendezvous, one reduction) and rank 0 prints the one JSON line with n_gpus 2."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["UNETK_BENCH_DRYRUN"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rank_sum"] == 3.0
+    sys.path.insert(0, repo)
+    import bench
+    envs = bench.rank_environments(4, 29999, base={})
+    assert [e["RANK"] for e in envs] == ["0", "1", "2", "3"] and all(e["WORLD_SIZE"] == "4" for e in envs)
+    assert all(e["MASTER_ADDR"] == "127.0.0.1" and e["LOCAL_RANK"] == e["RANK"] for e in envs)

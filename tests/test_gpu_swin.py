@@ -4,8 +4,10 @@ float32: outputs 1e-4 relative L2 (the stated bound).  Gradients are compared wi
 oracle: with batch statistics over a handful of elements in the decoder the fp32 gradients of the
 reference itself carry ~5e-3 of rounding noise (see tests/golden/make_golden.py), so the whole-model
 gradient bound is 2e-2 while every kernel is pinned on its own at 1e-4.
-bfloat16: single kernels 2e-2; the whole model in eval mode is printed and bounded at 5e-2 (bf16
-storage of a 12-block transformer plus an 9-conv decoder; the fp32 path is the parity reference).
+bfloat16: single kernels 2e-2; the whole model in eval mode 2e-2 (the stated bound; the reference's own
+bf16-autocast eval run is 2.03e-2..2.06e-2 from its fp32 run on these cases).  Training mode is bounded
+by the reference's bf16-autocast run frozen in tests/golden/bf16.npz (no worse than 1.3x its distance
+from fp32, with caps and a cosine floor).
 """
 import numpy as np
 import pytest
@@ -146,21 +148,45 @@ def test_swin_eval_forward(golden, dt, name, B, H, Wd):
     assert out.shape == ref.shape == (B, 1, H // 2, Wd // 2)
     e = rel(out, ref)
     print(f"swin eval {name} {dt}: rel {e:.2e}")
-    assert e < (1e-4 if dt == torch.float32 else 5e-2)
+    assert e < TOL[dt]
     if dt == torch.float32:
         assert rel(sub(out, 16384), golden("swin")[f"{name}.eval_out"]) < 1e-4
 
 
-@pytest.mark.parametrize("name,B,H,Wd", [("s64", 2, 64, 64), ("s128x64", 1, 128, 64)])
+def test_swin_eval_resized_skip_branch(golden):
+    """24-px input: 6x6 / 3x3 / 2x2 / 1x1 token grids (padded windows in every stage, odd-size merging
+    pad) and a decoder whose projected skips (3x3, 6x6) are bilinearly resized to the up-sampled size
+    (4x4, 8x8), swin_unet_model.py:526-529."""
+    x, _, _ = W.synthetic_batch(2, 4, 24, 24, seed=42)
+    for dt in DTYPES:
+        m, sd, cfg = build(dt)
+        m.eval()
+        out = m(x.cuda())
+        ref, _ = swin_oracle.swin_unet_forward(sd, x, cfg, False)
+        assert tuple(out.shape) == tuple(ref.shape) == tuple(golden("swin2")["s24.out_shape"])
+        e = rel(out, ref)
+        print(f"swin eval s24 {dt}: rel {e:.2e}")
+        assert e < TOL[dt]
+        if dt == torch.float32:
+            assert rel(sub(out, 16384), golden("swin2")["s24.eval_out"]) < 1e-4
+
+
+@pytest.mark.parametrize("name,B,H,Wd", [("s64", 2, 64, 64), ("s128x64", 1, 128, 64), ("s256", 1, 256, 256),
+                                          ("s24", 2, 24, 24)])
 def test_swin_train_forward_backward_fp32(golden, name, B, H, Wd):
-    g = golden("swin")
+    """s256 is BASELINE config 3's geometry (no padding, 64/16/4/1 windows per image); s24 takes the
+    padded-window path in every stage and the resized-skip decoder branch."""
+    g = golden("swin" if name in ("s64", "s128x64") else "swin2")
     m, sd, cfg = build(torch.float32)
     m.train()
     m.drop_path_override = [[None, None]] * sum(cfg["depths"])
     x, y, _ = W.synthetic_batch(B, 4, H, Wd, seed=42)
     xd = x.cuda().requires_grad_(True)
     out = m(xd)
-    tgt = F.avg_pool2d(y, 2)
+    if name in ("s64", "s128x64"):
+        tgt = F.avg_pool2d(y, 2)
+    else:
+        tgt = F.interpolate(y.double(), size=out.shape[-2:], mode="bilinear", align_corners=False).float()
     loss = ((out - tgt.cuda()) ** 2).mean()
     loss.backward()
     torch.cuda.synchronize()
@@ -189,6 +215,93 @@ def test_swin_train_forward_backward_fp32(golden, name, B, H, Wd):
     msd = m.state_dict()
     for k, v in o_stats.items():
         assert rel(msd[k], v) < 1e-4, k
+
+
+@pytest.mark.parametrize("name,B,H,Wd", [("s64", 2, 64, 64), ("s128x64", 1, 128, 64), ("s256", 1, 256, 256)])
+def test_swin_train_forward_backward_bf16(golden, name, B, H, Wd):
+    """bf16 storage (the benchmarked path, including the bf16-only fused weight + bias gradient of the
+    linear layers) against the fp32 oracle, bounded by the reference's own bf16-autocast run."""
+    from tests.test_gpu_unet import _cosine, bf16_bounds
+    gb = golden("bf16")
+    m, sd, cfg = build(torch.bfloat16)
+    m.train()
+    m.drop_path_override = [[None, None]] * sum(cfg["depths"])
+    x, y, _ = W.synthetic_batch(B, 4, H, Wd, seed=42)
+    xd = x.cuda().requires_grad_(True)
+    out = m(xd)
+    tgt = F.avg_pool2d(y, 2)
+    ((out - tgt.cuda()) ** 2).mean().backward()
+    torch.cuda.synchronize()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running_" not in k}
+    full = dict(sd)
+    full.update(params)
+    xo = x.clone().requires_grad_(True)
+    o_out, _ = swin_oracle.swin_unet_forward(full, xo, cfg, True, None)
+    ((o_out - tgt) ** 2).mean().backward()
+    names = [n for n, _ in m.named_parameters() if n != "final_conv.0.bias"]
+    mine = torch.cat([dict(m.named_parameters())[n].grad.double().cpu().reshape(-1) for n in names])
+    want = torch.cat([params[n].grad.double().reshape(-1) for n in names])
+    b_out, b_g, b_cos, b_dx, b_dxcos = bf16_bounds(gb, f"swin.{name}")
+    e_out, e_g, cos = rel(out, o_out), rel(mine, want), _cosine(mine, want)
+    e_dx, dxcos = rel(xd.grad, xo.grad), _cosine(xd.grad, xo.grad)
+    print(f"swin train {name} bf16 vs fp32: out {e_out:.3e} grads {e_g:.3f} cos {cos:.4f} dx {e_dx:.3f} cos {dxcos:.4f}; "
+          f"reference autocast out {float(gb[f'swin.{name}.out_rel']):.3e} grads {float(gb[f'swin.{name}.grad_rel']):.3f} "
+          f"cos {float(gb[f'swin.{name}.grad_cos']):.4f} dx {float(gb[f'swin.{name}.dx_rel']):.3f}")
+    assert e_out < b_out and e_g < b_g and cos > b_cos, (e_out, b_out, e_g, b_g, cos, b_cos)
+    assert e_dx < b_dx and dxcos > b_dxcos, (e_dx, b_dx, dxcos, b_dxcos)
+    assert float(m.final_conv[0].bias.grad.abs().max()) == 0.0
+
+
+def test_swin_training_step_matches_frozen_reference(golden):
+    """The Swin trainer's step (swin_unet_model.py:809-823): model, bilinear resize of the half-resolution
+    prediction to the label size, MultiLossFunction('tid_gradient'), backward, clip_grad_norm_(1.0),
+    AdamW(1e-4, 0.05), all on the HIP kernels, against the step frozen from the reference."""
+    from oracle import loss_oracle
+    from unet_amd import ops
+    from unet_amd.losses import MultiLossFunction
+    from unet_amd.optim import FusedAdamW
+    g = golden("step_swin")
+    m, sd, cfg = build(torch.float32)
+    m.train()
+    m.drop_path_override = [[None, None]] * sum(cfg["depths"])
+    x, y, w = W.synthetic_batch(2, 4, 64, 64, seed=42)
+    crit = MultiLossFunction(loss_oracle.preset("weighted_mse_grad", grad_w=0.3, spec_w=0.0)).cuda()
+    opt = FusedAdamW(m.parameters(), lr=1e-4, weight_decay=0.05, max_grad_norm=1.0)
+    outputs = m(x.cuda())
+    assert outputs.shape[-2:] == (32, 32)
+    outputs = ops.interpolate_bilinear(outputs, y.shape[-2:])
+    loss, parts = crit(outputs, y.cuda(), w.cuda())
+    opt.zero_grad()
+    loss.backward()
+    names = [str(s) for s in g["param_names"]]
+    now = dict(m.named_parameters())
+    gnorms = np.array([now[k].grad.double().norm().item() for k in names])
+    opt.step()
+    got = np.array([parts[k] for k in ("pixel", "gradient", "spectral", "total")])
+    assert rel(got, g["parts"]) < 1e-4
+    keep = np.array([k != "final_conv.0.bias" for k in names])
+    print("swin step: grad norm", opt.last_grad_norm.item(), "frozen", float(g["grad_norm"]),
+          "per-parameter norms rel", rel(gnorms[keep], g["grad_norms"][keep]))
+    assert abs(opt.last_grad_norm.item() - float(g["grad_norm"])) < 1e-2 * float(g["grad_norm"])
+    assert rel(gnorms[keep], g["grad_norms"][keep]) < 2e-2
+    delta = np.array([(now[k].detach().cpu() - sd[k]).double().norm().item() for k in names])
+    assert rel(delta[keep], g["param_delta_norms"][keep]) < 2e-2     # first Adam step ~ lr*sign(g): flips where g ~ 0
+    heads = np.concatenate([sub(now[k], 8) for k in names])
+    assert rel(heads, g["param_heads"]) < 1e-4
+
+
+def test_interpolate_bilinear_matches_torch():
+    from unet_amd import ops
+    for (h, w_, H, Wd) in ((32, 32, 64, 64), (7, 5, 16, 9), (12, 12, 12, 12), (16, 16, 8, 8)):
+        x = rnd((2, 1, h, w_), 11, torch.float32)
+        xr = x.clone().requires_grad_(True)
+        ref = F.interpolate(xr, size=(H, Wd), mode="bilinear", align_corners=False)
+        dy = rnd((2, 1, H, Wd), 12, torch.float32)
+        ref.backward(dy)
+        xd = x.cuda().requires_grad_(True)
+        out = ops.interpolate_bilinear(xd, (H, Wd))
+        out.backward(dy.cuda())
+        assert rel(out, ref) < 1e-6 and rel(xd.grad, xr.grad) < 1e-6, (h, w_, H, Wd)
 
 
 def test_swin_seeded_droppath_and_errors(golden):

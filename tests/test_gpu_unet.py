@@ -8,20 +8,21 @@ element changes a gradient discretely: the torch-CPU fp32 oracle itself differs 
 float64 run by 1.3e-3 (c1) to 7.5e-3 (f48) on these cases, so gradients are compared with the
 float64 oracle at 1e-2 on the wide cases and at 1e-4 on the narrow ones, where no flip occurs.
 
-bfloat16 path: eval outputs 2e-2 against the fp32 oracle (the stated bound).  In training mode
-bf16 STORAGE alone (bf16 activations and weights, fp32 accumulation and statistics) puts any
-pipeline 3e-2..7e-2 away from fp32 in the outputs and 0.35..0.6 in the gradients on these
-random weights and pure-noise targets: batch-statistic BatchNorm re-amplifies every layer's
-rounding and the gradient is a heavily cancelling sum.  Roundings are chaotic, so two correct
-bf16 pipelines also differ from each other by about that much and no bit-level bf16 model
-exists.  The oracle therefore has a mode that performs the same storage roundings on the CPU,
-and the GPU path must be NO FURTHER from the fp32 oracle than 1.3x that CPU bf16-storage model
-is (plus 2e-3): the kernels add nothing beyond the storage format.  Kernel arithmetic itself is
-pinned per op in test_gpu_ops.py (bf16 1e-2 on exactly representable inputs).
+bfloat16 path: eval outputs 2e-2 against the fp32 oracle (the stated bound).  In training mode the
+bound comes from the REFERENCE ITSELF: tests/golden/bf16.npz holds how far the reference modules,
+run under torch.autocast('cpu', dtype=torch.bfloat16), land from their own fp32 run on these same
+seeded cases (outputs 3.6e-2..7.0e-2, parameter gradients 0.39..0.58 relative L2 with cosine
+0.82..0.93: random weights and pure-noise targets make the gradient a heavily cancelling sum that
+batch-statistic BatchNorm re-amplifies).  The bf16 GPU path must be no further from fp32 than 1.3x
+those reference-run numbers, under absolute caps, with a cosine floor.  The oracle's CPU model of
+the storage roundings is printed next to it as a diagnostic only.  Kernel arithmetic itself is pinned
+per op in test_gpu_ops.py (bf16 1e-2 on exactly representable inputs), and
+test_bf16_loss_curve_tracks_fp32 checks the regime that matters for training: a learnable target.
 """
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import unet_oracle
 from oracle import weights as W
@@ -121,29 +122,121 @@ def _cat_grads(g, names):
     return torch.cat([g[n].double().reshape(-1) for n in names])
 
 
+def bf16_bounds(gb, prefix):
+    """(output, gradient, gradient-cosine, input-gradient, input-gradient-cosine) bounds for a bf16 run
+    against fp32, from the reference's own bf16-autocast run of the same case: 1.3x its distance,
+    capped; cosine no further below 1 than 1.3x."""
+    f = lambda k: float(gb[f"{prefix}.{k}"])
+    return (min(1.3 * f("out_rel") + 2e-3, 1e-1), min(1.3 * f("grad_rel"), 0.8),
+            max(1.0 - 1.3 * (1.0 - f("grad_cos")), 0.75), min(1.3 * f("dx_rel"), 0.85),
+            max(1.0 - 1.3 * (1.0 - f("dx_cos")), 0.70))
+
+
+def _cosine(a, b):
+    a, b = a.double().reshape(-1).cpu(), b.double().reshape(-1).cpu()
+    return (torch.dot(a, b) / (a.norm() * b.norm())).item()
+
+
 @pytest.mark.parametrize("name", ["small", "ragged", "odd", "f48", "c1"])
 def test_train_forward_backward_bf16(golden, name):
     dt = torch.bfloat16
+    gb = golden("bf16")
     m, sd, x, y, xd, out, loss = _run_train(name, dt)
     lf = lambda o: ((o - y) ** 2).mean()
     f_out, f_loss, f_g, f_stats = unet_oracle.unet_fwd_bwd(sd, x, lf)               # fp32 model
-    e_out, e_loss, e_g, e_stats = unet_oracle.unet_fwd_bwd(sd, x, lf, None, True)   # bf16-storage model on CPU
+    e_out, e_loss, e_g, e_stats = unet_oracle.unet_fwd_bwd(sd, x, lf, None, unet_oracle.BF16_ALL)   # diagnostic
     names = [n for n, _ in m.named_parameters()]
     mine_g = torch.cat([p.grad.double().cpu().reshape(-1) for _, p in m.named_parameters()])
     ref_g, emu_g = _cat_grads(f_g, names), _cat_grads(e_g, names)
-    out_gpu, out_emu = rel(out, f_out), rel(e_out, f_out)
-    g_gpu, g_emu = rel(mine_g, ref_g), rel(emu_g, ref_g)
-    dx_gpu, dx_emu = rel(xd.grad, f_g["__input__"]), rel(e_g["__input__"], f_g["__input__"])
-    cos = torch.dot(mine_g, ref_g) / (mine_g.norm() * ref_g.norm())
-    print(f"train {name} bf16 vs fp32: out gpu {out_gpu:.2e} / cpu-bf16 {out_emu:.2e}; grads gpu {g_gpu:.2e} / "
-          f"cpu-bf16 {g_emu:.2e}; dx gpu {dx_gpu:.2e} / cpu-bf16 {dx_emu:.2e}; cos {cos:.3f}")
-    assert out_gpu < 1.3 * out_emu + 2e-3 and out_gpu < 1e-1
-    assert g_gpu < 1.3 * g_emu + 2e-3
-    assert dx_gpu < 1.3 * dx_emu + 2e-3
+    out_gpu, g_gpu, dx_gpu = rel(out, f_out), rel(mine_g, ref_g), rel(xd.grad, f_g["__input__"])
+    cos, dx_cos = _cosine(mine_g, ref_g), _cosine(xd.grad, f_g["__input__"])
+    b_out, b_g, b_cos, b_dx, b_dxcos = bf16_bounds(gb, f"unet.{name}")
+    print(f"train {name} bf16 vs fp32: out {out_gpu:.3e} (reference autocast {float(gb[f'unet.{name}.out_rel']):.3e}, "
+          f"cpu storage model {rel(e_out, f_out):.3e}); grads {g_gpu:.3f} cos {cos:.3f} (reference "
+          f"{float(gb[f'unet.{name}.grad_rel']):.3f} / {float(gb[f'unet.{name}.grad_cos']):.3f}, model {rel(emu_g, ref_g):.3f}); "
+          f"dx {dx_gpu:.3f} cos {dx_cos:.3f} (reference {float(gb[f'unet.{name}.dx_rel']):.3f})")
+    assert out_gpu < b_out, (out_gpu, b_out)
+    assert g_gpu < b_g and cos > b_cos, (g_gpu, b_g, cos, b_cos)
+    assert dx_gpu < b_dx and dx_cos > b_dxcos, (dx_gpu, b_dx, dx_cos, b_dxcos)
     assert abs(loss.item() - f_loss.item()) < 5e-2 * abs(f_loss.item())
     msd = m.state_dict()
     for k, v in f_stats.items():
-        assert rel(msd[k], v) < 1.3 * rel(e_stats[k], v) + 2e-3, k
+        assert rel(msd[k], v) < 2e-2, k
+
+
+def test_bf16_loss_curve_tracks_fp32():
+    """The regime that matters: a learnable target (a fixed smooth function of the input), 20 optimiser
+    steps from the same initialisation in fp32 and in bf16 storage.  The two loss curves must agree within
+    5 % at every step and both must learn (final loss below 60 % of the first)."""
+    from unet_amd import OptimizedUNet
+    from unet_amd.optim import FusedAdamW
+    torch.manual_seed(7)
+    B, H, Wd = 8, 64, 64
+    x = F.avg_pool2d(torch.randn(B, 4, H + 4, Wd + 4), 5, 1)            # smooth inputs
+    x = x / x.std()
+    y = torch.tanh(0.8 * x[:, :1] - 0.6 * x[:, 1:2] * x[:, 2:3]) + 0.3 * F.avg_pool2d(F.pad(x[:, 3:4], (1, 1, 1, 1)), 3, 1)
+    init = OptimizedUNet(4, 1, 16).state_dict()
+    curves = {}
+    for dt in (torch.float32, torch.bfloat16):
+        m = OptimizedUNet(4, 1, 16, compute_dtype=dt)
+        m.load_state_dict(init)
+        m = m.cuda().train()
+        m.dropout_masks_override = [None] * 9
+        opt = FusedAdamW(m.parameters(), lr=1e-3, weight_decay=5e-5, max_grad_norm=1.0)
+        xd, yd = x.cuda(), y.cuda()
+        losses = []
+        for _ in range(20):
+            opt.zero_grad()
+            loss = ((m(xd) - yd) ** 2).mean()
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        curves[dt] = np.array(losses)
+    f32, b16 = curves[torch.float32], curves[torch.bfloat16]
+    dev = np.abs(b16 - f32) / f32
+    print("fp32 loss curve", np.round(f32, 4).tolist())
+    print("bf16 loss curve", np.round(b16, 4).tolist(), "max deviation", dev.max())
+    assert f32[-1] < 0.6 * f32[0] and b16[-1] < 0.6 * b16[0]
+    assert dev.max() < 5e-2, dev
+
+
+def test_config2_full_size_properties(golden):
+    """BASELINE config 2 at full size (batch 64 of 4x256x256, UNet(4,1,48)), where the CPU oracle is too
+    slow: (1) eval mode is per-sample, so the first samples of the batch-64 run equal a batch-3 run bit
+    for bit (exercises the >=256-workgroup XCD-aware tile order against the small-grid order);
+    (2) one bf16 training step against the fp32 GPU step (itself pinned to the oracle at small sizes):
+    outputs, gradients and their cosine within the bounds frozen from the reference's bf16-autocast run of
+    the same network (case f48); (3) the split-output data gradients at 144/288/576/1152 channels give
+    finite, non-zero gradients for every parameter."""
+    from unet_amd import OptimizedUNet
+    sd = W.fill_state_dict(W.unet_template(4, 1, 48), seed=42)
+    x, y, _ = W.synthetic_batch(64, 4, 256, 256, seed=42)
+    xd, yd = x.cuda(), y.cuda()
+    res = {}
+    for dt in (torch.bfloat16, torch.float32):
+        m = OptimizedUNet(4, 1, 48, compute_dtype=dt)
+        m.load_state_dict(sd)
+        m = m.cuda()
+        m.eval()
+        full = m(xd)
+        few = m(xd[:3])
+        assert torch.equal(full[:3], few), dt
+        m.train()
+        m.dropout_masks_override = [None] * 9
+        out = m(xd)
+        ((out - yd) ** 2).mean().backward()
+        torch.cuda.synchronize()
+        res[dt] = (out.detach().cpu(), torch.cat([p.grad.double().cpu().reshape(-1) for p in m.parameters()]))
+        for n, p in m.named_parameters():
+            assert torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0, n
+        del m, out, full, few
+        torch.cuda.empty_cache()
+    (o16, g16), (o32, g32) = res[torch.bfloat16], res[torch.float32]
+    b_out, b_g, b_cos, _, _ = bf16_bounds(golden("bf16"), "unet.f48")
+    e_out, e_g, cos = rel(o16, o32), rel(g16, g32), _cosine(g16, g32)
+    print(f"config 2 full size, bf16 vs fp32 on the GPU: out {e_out:.3e} grads {e_g:.3f} cos {cos:.3f} "
+          f"(bounds {b_out:.3e} / {b_g:.3f} / {b_cos:.3f})")
+    assert e_out < b_out and e_g < b_g and cos > b_cos
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
@@ -159,8 +252,7 @@ def test_seeded_dropout_masks(golden, dt):
         assert rel(out, ref) < 1e-4
         assert rel(sub(out, 16384), golden("unet")["small.dropout_seed1234_out"]) < 1e-4
     else:
-        emu, _ = unet_oracle.unet_forward(sd, x, True, masks, True)
-        assert rel(out, ref) < 1.3 * rel(emu, ref) + 2e-3
+        assert rel(out, ref) < bf16_bounds(golden("bf16"), "unet.small")[0]
     # fresh draws: about 5 % of the channels of every block are dropped, survivors scaled by 1/0.95
     m.dropout_masks_override = None
     ks = m._draw_masks(64, torch.device("cuda"))

@@ -64,11 +64,14 @@ _SIGNATURES = {
     "unetk_pool_bwd": (I, [P, P, P, P, I, P, I, I, I, I, I, P]),
     "unetk_upsample_concat_fwd": (I, [P, I, I, I, P, I, I, P, I, I, I, I, P]),
     "unetk_upsample_bwd": (I, [P, I, I, I, P, I, I, I, I, I, P]),
+    "unetk_resize_planes_f32": (I, [P, P, L, I, I, I, I, I, P]),
     "unetk_head1x1_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, P]),
     "unetk_head1x1_bwd": (I, [P, I, P, P, P, P, P, I, I, I, I, I, I, P, I, P]),
     "unetk_loss_num_partials": (I, [I, I, I]),
     "unetk_loss_spectral_blocks": (I, [I, I]),
     "unetk_loss_pixgrad_fwd": (I, [P, P, P, I, I, I, I, I, I, F, P, P, P, P, P]),
+    "unetk_loss_static_max_pixels": (L, []),
+    "unetk_loss_pixgrad_fwd_static": (I, [P, P, P, I, I, I, I, I, I, F, P, P, P, P]),
     "unetk_loss_spectral_fwd": (I, [P, P, P, I, I, I, F, P, P, P, P, P]),
     "unetk_loss_combine": (I, [P, F, F, F, I, I, P]),
     "unetk_loss_pixgrad_bwd": (I, [P, P, P, I, I, I, I, I, P, P, P, P, F, F, I, P, I, P]),

@@ -13,6 +13,8 @@
 //   [4] c_pix  [5] pix_weighted   d pixel/d pred = c_pix * (pix_weighted ? w : 1) * dL/dd, w>0 only when weighted
 //   [6] c_grad [7] grad_weighted
 //   [8] c_dx [9] dx_weighted [10] c_dy [11] dy_weighted     (forward-difference method)
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -352,6 +354,40 @@ inline LossCfg make_cfg(int B, int H, int W, int pixel_mae, int grad_method, int
   return c;
 }
 
+// Partial sums of unetk_loss_pixgrad_fwd_static: device memory that belongs to the library, one
+// copy per GPU, sized for the largest launch (loss_blocks never exceeds MAX_LOSS_BLOCKS).
+constexpr int MAX_LOSS_BLOCKS = 1024;
+constexpr long MAX_STATIC_PIXELS = 1L << 30;
+static __device__ __align__(256) float scratch[MAX_LOSS_BLOCKS * NQ];
+
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mu;
+float* g_scratch_ptr[MAX_DEVICES];      // device address of `scratch` on each GPU, looked up once
+
+// The array's name is only a host-side handle: kernels must be given its device address.
+int scratch_address(float** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess || dev < 0 || dev >= MAX_DEVICES) {
+    unetk_set_error("loss_pixgrad_fwd_static: hipGetDevice failed or device index %d outside [0,%d)", dev,
+                    MAX_DEVICES);
+    return UNETK_EHIP;
+  }
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (g_scratch_ptr[dev] == nullptr) {
+    float* p = nullptr;
+    e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || p == nullptr) {
+      unetk_set_error("loss_pixgrad_fwd_static: hipGetSymbolAddress failed on device %d: %s", dev,
+                      hipGetErrorString(e));
+      return UNETK_EHIP;
+    }
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return UNETK_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -372,6 +408,35 @@ int unetk_loss_pixgrad_fwd(const float* pred, const float* target, const float* 
   LossCfg c = make_cfg(B, H, W, pixel_mae, grad_method, pixel_use_w && w != nullptr, w != nullptr, tid_scale,
                        0.f, 0.f, 0.f, 0.f);
   const int nblk = loss_blocks((long)B * H * W);
+  hipLaunchKernelGGL(pixgrad_fwd_kernel, dim3(nblk), dim3(LT), 0, stream, pred, target, w, c, gx, gy, partials);
+  UNETK_CHECK_LAUNCH();
+  hipLaunchKernelGGL(pixgrad_finalize_kernel, dim3(1), dim3(LT), 0, stream, partials, nblk, c, res);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int64_t unetk_loss_static_max_pixels(void) { return MAX_STATIC_PIXELS; }
+
+int unetk_loss_pixgrad_fwd_static(const float* pred, const float* target, const float* w, int B, int H, int W,
+                                  int pixel_mae, int grad_method, int pixel_use_w, float tid_scale, float* gx,
+                                  float* gy, float* res, hipStream_t stream) {
+  UNETK_CHECK_ARG(pred && target && res, "loss_pixgrad_fwd_static: null pointer");
+  UNETK_CHECK_ARG(grad_method >= 0 && grad_method <= 2, "loss_pixgrad_fwd_static: gradient method %d", grad_method);
+  UNETK_CHECK_ARG(grad_method != 1 || (gx && gy), "loss_pixgrad_fwd_static: Sobel maps required");
+  UNETK_CHECK_ARG(B > 0 && H > 0 && W > 0, "loss_pixgrad_fwd_static: bad shape");
+  const long npix = (long)B * H * W;
+  UNETK_CHECK_ARG(npix <= MAX_STATIC_PIXELS,
+                  "loss_pixgrad_fwd_static: %ld pixels exceed the %ld this entry point is built for; use "
+                  "unetk_loss_pixgrad_fwd with a caller-owned partials buffer", npix, MAX_STATIC_PIXELS);
+  const int nblk = loss_blocks(npix);
+  UNETK_CHECK_ARG(nblk <= MAX_LOSS_BLOCKS, "loss_pixgrad_fwd_static: %d partial sums exceed the library's %d", nblk,
+                  MAX_LOSS_BLOCKS);
+  float* partials = nullptr;
+  const int rc = scratch_address(&partials);
+  if (rc != UNETK_OK) return rc;
+  LossCfg c = make_cfg(B, H, W, pixel_mae, grad_method, pixel_use_w && w != nullptr, w != nullptr, tid_scale,
+                       0.f, 0.f, 0.f, 0.f);
+  // every partial the finalize kernel reads is written by this launch first: nothing to clear
   hipLaunchKernelGGL(pixgrad_fwd_kernel, dim3(nblk), dim3(LT), 0, stream, pred, target, w, c, gx, gy, partials);
   UNETK_CHECK_LAUNCH();
   hipLaunchKernelGGL(pixgrad_finalize_kernel, dim3(1), dim3(LT), 0, stream, partials, nblk, c, res);

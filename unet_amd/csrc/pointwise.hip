@@ -794,6 +794,63 @@ __global__ void upsample_bwd_kernel(const T* __restrict__ dout, int ldout, int H
   store16(dlow + (size_t)p * C1 + cg * E, o);
 }
 
+// ------------------------------------------------------------------ planar fp32 resize (model outputs)
+// F.interpolate(outputs, size=labels.shape[-2:], mode='bilinear', align_corners=False) on the
+// (B,1,h,w) fp32 prediction, swin_unet_model.py:812-814: one thread per output pixel.
+__global__ void resize_planes_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, long total, int h,
+                                         int w, int H, int W, float sy, float sx) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int x = idx % W;
+  const int y = (idx / W) % H;
+  const long pl = idx / ((long)W * H);
+  int y0, y1, x0, x1;
+  float ly, lx;
+  src_index(sy, y, h, y0, y1, ly);
+  src_index(sx, x, w, x0, x1, lx);
+  const float* base = in + pl * h * w;
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  out[idx] = hy * (hx * base[(long)y0 * w + x0] + lx * base[(long)y0 * w + x1]) +
+             ly * (hx * base[(long)y1 * w + x0] + lx * base[(long)y1 * w + x1]);
+}
+
+// din[pl,i,j] = sum over the output pixels (y,x) that read (i,j) of wy*wx*dout[pl,y,x]: a gather in a
+// fixed order, so the result does not depend on scheduling.
+__global__ void resize_planes_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, long total, int h,
+                                         int w, int H, int W, float sy, float sx) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int j = idx % w;
+  const int i = (idx / w) % h;
+  const long pl = idx / ((long)w * h);
+  int ylo = (int)floorf(((float)i - 0.5f) / sy - 0.5f) - 1;
+  int yhi = (int)ceilf(((float)i + 1.5f) / sy - 0.5f) + 1;
+  int xlo = (int)floorf(((float)j - 0.5f) / sx - 0.5f) - 1;
+  int xhi = (int)ceilf(((float)j + 1.5f) / sx - 0.5f) + 1;
+  if (ylo < 0) ylo = 0;
+  if (xlo < 0) xlo = 0;
+  if (yhi > H - 1) yhi = H - 1;
+  if (xhi > W - 1) xhi = W - 1;
+  const float* base = dout + pl * H * W;
+  float acc = 0.f;
+  for (int y = ylo; y <= yhi; ++y) {
+    int y0, y1;
+    float ly;
+    src_index(sy, y, h, y0, y1, ly);
+    const float wy = (y0 == i ? 1.f - ly : 0.f) + (y1 == i ? ly : 0.f);
+    if (wy == 0.f) continue;
+    for (int x = xlo; x <= xhi; ++x) {
+      int x0, x1;
+      float lx;
+      src_index(sx, x, w, x0, x1, lx);
+      const float wx = (x0 == j ? 1.f - lx : 0.f) + (x1 == j ? lx : 0.f);
+      if (wx == 0.f) continue;
+      acc += wy * wx * base[(long)y * W + x];
+    }
+  }
+  din[idx] = acc;
+}
+
 // ------------------------------------------------------------------ final 1x1 convolution (few outputs)
 // out[b,o,hw] = bias[o] + sum_c x[b,hw,c] * w[o,c]      (out is NCHW fp32)
 template <typename T>
@@ -1070,6 +1127,26 @@ int unetk_upsample_bwd(const void* dout, int ldout, int H, int W, void* dlow, in
   UNETK_CHECK_ARG(total < (1L << 31), "upsample_bwd: tensor too large");
   DISPATCH_T(dtype, hipLaunchKernelGGL(upsample_bwd_kernel<T>, dim3(8 * cdiv(cdiv(total, 256), 8)), dim3(256), 0, stream,
                                        (const T*)dout, ldout, H, W, (T*)dlow, B, h, w, C1, sy, sx));
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_resize_planes_f32(const float* in, float* out, int64_t planes, int h, int w, int H, int W, int backward,
+                            hipStream_t stream) {
+  UNETK_CHECK_ARG(in && out, "resize_planes_f32: null pointer");
+  UNETK_CHECK_ARG(planes > 0 && h > 0 && w > 0 && H > 0 && W > 0, "resize_planes_f32: bad shape");
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  if (!backward) {
+    const long total = planes * H * W;
+    UNETK_CHECK_ARG(total < (1L << 40), "resize_planes_f32: tensor too large");
+    hipLaunchKernelGGL(resize_planes_fwd_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, in, out,
+                       total, h, w, H, W, sy, sx);
+  } else {   // in = gradient of the (planes,H,W) result, out = gradient of the (planes,h,w) source
+    const long total = planes * h * w;
+    UNETK_CHECK_ARG(total < (1L << 40), "resize_planes_f32: tensor too large");
+    hipLaunchKernelGGL(resize_planes_bwd_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, in, out,
+                       total, h, w, H, W, sy, sx);
+  }
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }

@@ -15,6 +15,21 @@ BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
 
+class GradOut(dict):
+    """Parameter gradients by name, as a whole-network backward produces them.  With a sink (the
+    data-parallel reducer's ``grad_sink(name, tensor) -> tensor``) every gradient is handed over the
+    moment its kernel is queued, so its bucket's all-reduce can start while the backward continues."""
+
+    def __init__(self, sink=None):
+        super().__init__()
+        self.sink = sink
+
+    def __setitem__(self, name, grad):
+        if self.sink is not None and grad is not None:
+            grad = self.sink(name, grad)
+        dict.__setitem__(self, name, grad)
+
+
 def _vec(dt):
     return 8 if dt == torch.bfloat16 else 4
 
@@ -338,6 +353,36 @@ def upsample_bwd(dcat, C1, h, w):
     dlow = torch.empty((B, h, w, C1), dtype=dcat.dtype, device=dcat.device)
     call("unetk_upsample_bwd", ptr(dcat), ld, H, W, ptr(dlow), B, h, w, C1, dtype_code(dcat.dtype), stream())
     return dlow
+
+
+class _ResizePlanes(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, H, W):
+        B, C, h, w = x.shape
+        xin = x.detach().contiguous().float()
+        out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+        call("unetk_resize_planes_f32", ptr(xin), ptr(out), B * C, h, w, H, W, 0, stream())
+        ctx.shape = (B, C, h, w, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, h, w, H, W = ctx.shape
+        g = g.detach().contiguous().float()
+        dx = torch.empty((B, C, h, w), dtype=torch.float32, device=g.device)
+        call("unetk_resize_planes_f32", ptr(g), ptr(dx), B * C, h, w, H, W, 1, stream())
+        return dx, None, None
+
+
+def interpolate_bilinear(x: torch.Tensor, size) -> torch.Tensor:
+    """``F.interpolate(x, size=size, mode='bilinear', align_corners=False)`` for an fp32 NCHW tensor on
+    the GPU, with autograd: what the Swin trainer applies to the half-resolution prediction before the
+    loss (swin_unet_model.py:812-814)."""
+    _require_cuda(x, "input")
+    if x.dim() != 4:
+        raise RuntimeError(f"expected (B,C,h,w), got {tuple(x.shape)}")
+    H, W = int(size[0]), int(size[1])
+    return _ResizePlanes.apply(x, H, W)
 
 
 def head1x1_fwd(x, w, bias):

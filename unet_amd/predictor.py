@@ -10,7 +10,10 @@ With ``torch.distributed`` initialised the tile rows are split into contiguous b
 rank; a rank receives the partially accumulated overlap strip from the rank above it, adds its own
 tiles in order and passes its own bottom strip on, which keeps the single-process order (and bits).
 """
+import logging
 import os
+import pickle
+import re
 from typing import List, Optional, Tuple
 
 import numpy as np
@@ -20,6 +23,69 @@ from . import _lib, ops
 from ._lib import call, ptr, stream, dtype_code
 
 FEATURE_VARS = ("GA", "DOV_EW", "DOV_NS", "VGG")    # large_area_predictor.py:161
+logger = logging.getLogger("unet_amd.predictor")
+
+
+# ------------------------------------------------------------------ checkpoints without execution
+class InertObject:
+    """Stands in for an instance of a class a checkpoint pickled (the trainer's config object,
+    enhanced_training_multi_loss.py:964).  The unpickler creates it without calling anything and
+    stores the pickled attributes; using the class as a function (a REDUCE of an arbitrary callable)
+    is refused, which fails the load."""
+
+    def __init__(self, *args, **kwargs):
+        raise pickle.UnpicklingError(f"checkpoint calls the global {type(self).__module__}."
+                                     f"{type(self).__qualname__}: refused (only class instances are tolerated)")
+
+    def __setstate__(self, state):
+        if isinstance(state, dict):
+            self.__dict__.update(state)
+        else:
+            self.__dict__["state"] = state
+
+
+class InertValue:
+    """Stands in for the numpy reconstructors behind a pickled numpy scalar, dtype or array
+    (the training history holds np.float64 correlations, :889, :925): calling them yields an inert
+    placeholder instead of running numpy code on file contents."""
+
+    def __init__(self, *args, **kwargs):
+        self.args = args
+
+    def __setstate__(self, state):
+        self.state = state
+
+
+_NUMPY_VALUE_GLOBALS = (
+    "numpy.core.multiarray.scalar", "numpy._core.multiarray.scalar", "numpy.dtype",
+    "numpy.core.multiarray._reconstruct", "numpy._core.multiarray._reconstruct", "numpy.ndarray",
+)
+_UNSUPPORTED_GLOBAL = re.compile(r"Unsupported global: GLOBAL (\S+) was not an allowed global")
+
+
+def _inert_stub(qualified: str):
+    module, _, name = qualified.rpartition(".")
+    base = InertValue if qualified in _NUMPY_VALUE_GLOBALS else InertObject
+    return type(name, (base,), {"__module__": module, "__qualname__": name})
+
+
+def load_checkpoint(path: str, max_globals: int = 64):
+    """``torch.load(path, map_location='cpu', weights_only=True)`` that also reads checkpoints holding
+    instances of classes this process cannot (and must not) import.  Every global the weights-only
+    unpickler rejects is registered as an inert stand-in under its pickled qualified name and the load
+    is retried: class instances become attribute bags, numpy scalars placeholders, and a pickle that
+    CALLS an unknown global (os.system and the like) is refused.  No code from the file or from the
+    modules it names is imported or run."""
+    stubs = {}
+    while True:
+        try:
+            with torch.serialization.safe_globals(list(stubs.values())):
+                return torch.load(path, map_location="cpu", weights_only=True)
+        except pickle.UnpicklingError as e:
+            m = _UNSUPPORTED_GLOBAL.search(str(e))
+            if m is None or m.group(1) in stubs or len(stubs) >= max_globals:
+                raise
+            stubs[m.group(1)] = _inert_stub(m.group(1))
 
 
 class LargeAreaPredictionConfig:
@@ -109,11 +175,12 @@ class LargeAreaPredictor:
     def load_model(self, model_path: str, device: Optional[torch.device] = None, compute_dtype=torch.bfloat16):
         """large_area_predictor.py:83-106: build ``OptimizedUNet(IN_CHANNELS, OUT_CHANNELS, INIT_FEATURES)``,
         load ``checkpoint['model_state_dict']`` (or the bare state dict), eval mode; ``None`` on any failure,
-        as the reference.  Checkpoints are read with ``weights_only=True``: a file that pickles arbitrary
-        objects next to the tensors is refused rather than executed (and yields ``None``)."""
+        as the reference (the reason is logged).  The file is read by ``load_checkpoint``: nothing in it is
+        executed, and the trainer's own checkpoints, which pickle a config class instance and numpy scalars
+        next to the tensors (enhanced_training_multi_loss.py:956-971), load."""
         from .unet import OptimizedUNet
         try:
-            ckpt = torch.load(model_path, map_location="cpu", weights_only=True)
+            ckpt = load_checkpoint(model_path)
             model = OptimizedUNet(in_channels=self.config.IN_CHANNELS, out_channels=self.config.OUT_CHANNELS,
                                   init_features=self.config.INIT_FEATURES, compute_dtype=compute_dtype)
             model.load_state_dict(ckpt["model_state_dict"] if "model_state_dict" in ckpt else ckpt)
@@ -122,7 +189,8 @@ class LargeAreaPredictor:
             model.to(device)
             model.eval()
             return model
-        except Exception:
+        except Exception as e:      # the reference swallows every failure and returns None (:104-106)
+            logger.error("load_model(%s) failed: %s: %s", model_path, type(e).__name__, e)
             return None
 
     def save_prediction(self, prediction: np.ndarray, features, model_name: str) -> str:
@@ -227,10 +295,16 @@ class LargeAreaPredictor:
         out_map = be.normalize(acc, cnt)
         if world == 1:
             return out_map
-        # rank r owns the rows from its band's first row to the next band's first row (last: to the end)
-        own0 = row0 if rank > 0 else 0
-        own1 = bands[rank + 1][0] * S if rank < world - 1 else lat
-        full = torch.zeros((lat, lon), dtype=torch.float32, device=dev)
-        full[own0:own1] = out_map[own0:own1]
-        dist.all_reduce(full)            # disjoint row ownership: the sum only assembles the map
+        # rank r owns the rows from its band's first row to the next band's first row (last: to the end);
+        # the map is assembled by an all-gather of the owned rows (padded to the tallest band)
+        owned = [(bands[r][0] * S if r > 0 else 0, bands[r + 1][0] * S if r < world - 1 else lat) for r in range(world)]
+        tall = max(b - a for a, b in owned)
+        own0, own1 = owned[rank]
+        mine = torch.zeros((tall, lon), dtype=torch.float32, device=dev)
+        mine[:own1 - own0] = out_map[own0:own1]
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        full = torch.empty((lat, lon), dtype=torch.float32, device=dev)
+        for (a, b), part in zip(owned, parts):
+            full[a:b] = part[:b - a]
         return full

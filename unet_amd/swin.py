@@ -147,6 +147,8 @@ class SwinUNet(nn.Module):
         self.apply(self._init_weights)
         # test hook: per block [keep1, keep2] (B,) DropPath scales (or None) used instead of fresh draws
         self.drop_path_override: Optional[List] = None
+        # data-parallel hook, see unet_amd.dist.GradReducer
+        self.grad_sink = None
 
     def _init_weights(self, m):
         # reference swin_unet_model.py:616-630 (ConvTranspose2d is not a Conv2d: keeps its default init)
@@ -196,46 +198,53 @@ class SwinUNet(nn.Module):
 
 
 # ------------------------------------------------------------------ packed weights
-# The packed forms of every Linear / Conv2d weight are made by ONE launch at the start of a forward
-# (forward form, and for training the data-gradient form) and looked up by the parameter's address
-# where a layer needs them; anything not found there (a reshaped copy) is packed on the spot.
-_POOL: Dict = {}
+class _Ctx:
+    """What one forward (and its backward) carries around: the compute dtype and the packed forms of
+    every Linear / Conv2d weight, made by ONE launch at the start of the forward (forward form, and
+    for training the data-gradient form) and looked up by the parameter's address; anything not
+    found there (a reshaped copy) is packed on the spot.  Owned by the autograd node of the step
+    (or dropped after an inference call): interleaved models or steps cannot see each other's packs."""
+    __slots__ = ("dt", "pool")
+
+    def __init__(self, model, training):
+        self.dt = dt = model.compute_dtype
+        ws = []
+        for m in model.modules():
+            if isinstance(m, (nn.Linear, nn.Conv2d)):
+                w = m.weight
+                if w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and \
+                        (w.dim() == 2 or (w.shape[2] == w.shape[3] and w.shape[2] in (1, 3))):
+                    ws.append(w)
+        forms = (False, True) if training else (False,)
+        packs = ops.pack_many([(w, tr) for tr in forms for w in ws], dt)
+        self.pool = {}
+        for i, tr in enumerate(forms):
+            for j, w in enumerate(ws):
+                self.pool[(w.data_ptr(), tr)] = (packs[i * len(ws) + j], w.shape[0], w.shape[1],
+                                                 1 if w.dim() == 2 else w.shape[2], w._version)
+
+    def packed(self, w, transpose=False):
+        hit = self.pool.get((w.data_ptr(), bool(transpose)))
+        ks = 1 if w.dim() == 2 else w.shape[2]
+        if hit is not None and hit[1:4] == (w.shape[0], w.shape[1], ks):
+            if hit[4] != w._version:
+                raise RuntimeError("a SwinUNet parameter was modified in place between the forward pass and its "
+                                   "backward pass (the packed copy made by the forward no longer matches it)")
+            return hit[0]
+        return ops.PackedConv(w, self.dt, transpose=transpose)
 
 
-def _prepack(model, dt, training):
-    global _POOL
-    ws = []
-    for m in model.modules():
-        if isinstance(m, (nn.Linear, nn.Conv2d)):
-            w = m.weight
-            if w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and \
-                    (w.dim() == 2 or (w.shape[2] == w.shape[3] and w.shape[2] in (1, 3))):
-                ws.append(w)
-    forms = (False, True) if training else (False,)
-    packs = ops.pack_many([(w, tr) for tr in forms for w in ws], dt)
-    pool = {}
-    for i, tr in enumerate(forms):
-        for j, w in enumerate(ws):
-            pool[(w.data_ptr(), tr)] = (packs[i * len(ws) + j], w.shape[0], w.shape[1], 1 if w.dim() == 2 else w.shape[2], dt)
-    _POOL = pool
-    return pool
-
-
-def _packed(w, dt, transpose=False):
-    hit = _POOL.get((w.data_ptr(), bool(transpose)))
-    ks = 1 if w.dim() == 2 else w.shape[2]
-    if hit is not None and hit[1:] == (w.shape[0], w.shape[1], ks, dt):
-        return hit[0]
-    return ops.PackedConv(w, dt, transpose=transpose)
+def _linear_launch(x, pw, **kw):
+    """Every token-linear GEMM launch (forward and data gradient) goes through here."""
+    return ops.conv_fwd(x, pw, **kw)[0]
 
 
 # ------------------------------------------------------------------ building blocks
-def _linear(x, w, b, dt, act=0, resid=None, keep=None, out=None):
-    return ops.conv_fwd(x, _packed(w, dt), scale=None, shift=b, act=act, resid=resid, resid_keep=keep,
-                        out=out)[0]
+def _linear(x, w, b, cx, act=0, resid=None, keep=None, out=None):
+    return _linear_launch(x, cx.packed(w), scale=None, shift=b, act=act, resid=resid, resid_keep=keep, out=out)
 
 
-def _linear_bwd(x, dy, w, dt, grads, wname, bname, need_dx=True):
+def _linear_bwd(x, dy, w, cx, grads, wname, bname, need_dx=True):
     Co, Ci = w.shape[0], w.shape[1]
     if bname is not None:
         dw, grads[bname] = ops.linear_wgrad(x, dy, Ci, Co)
@@ -243,7 +252,7 @@ def _linear_bwd(x, dy, w, dt, grads, wname, bname, need_dx=True):
     else:
         grads[wname] = ops.conv_wgrad(x, dy, Ci, Co, 1).view(w.shape)
     if need_dx:
-        return ops.conv_fwd(dy, _packed(w.view(Co, Ci), dt, transpose=True))[0]
+        return _linear_launch(dy, cx.packed(w.view(Co, Ci), transpose=True))
     return None
 
 
@@ -263,7 +272,7 @@ def _pad_tokens(t, He, We):
     return p
 
 
-def _block_fwd(blk, pre, x, keep1, keep2, dt, save):
+def _block_fwd(blk, pre, x, keep1, keep2, cx, save):
     """One SwinTransformerBlock (:305-374) on tokens x (B,H,W,C)."""
     B, H, W, C = x.shape
     _check_grid(H, W)
@@ -272,42 +281,42 @@ def _block_fwd(blk, pre, x, keep1, keep2, dt, save):
     a = blk.attn
     ln1, m1, r1 = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
     ln1p = _pad_tokens(ln1, He, We)
-    qkv = _linear(ln1p, a.qkv.weight, a.qkv.bias, dt)
+    qkv = _linear(ln1p, a.qkv.weight, a.qkv.bias, cx)
     # the shift mask is built for every stage and handed to every block, shifted or not (:458-484)
     att = ops.window_attn_fwd(qkv, a.relative_position_bias_table, a.num_heads, blk.shift_size, True)
     if not padded:
-        x1 = _linear(att, a.proj.weight, a.proj.bias, dt, resid=x, keep=keep1)
+        x1 = _linear(att, a.proj.weight, a.proj.bias, cx, resid=x, keep=keep1)
     else:
-        pr = _linear(att, a.proj.weight, a.proj.bias, dt)
+        pr = _linear(att, a.proj.weight, a.proj.bias, cx)
         x1 = ops.scale_sample(pr[:, :H, :W].contiguous(), keep1, x)
     ln2, m2, r2 = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
-    hpre = _linear(ln2, blk.mlp[0].weight, blk.mlp[0].bias, dt)
+    hpre = _linear(ln2, blk.mlp[0].weight, blk.mlp[0].bias, cx)
     hact = ops.gelu_fwd(hpre)
-    x2 = _linear(hact, blk.mlp[3].weight, blk.mlp[3].bias, dt, resid=x1, keep=keep2)
+    x2 = _linear(hact, blk.mlp[3].weight, blk.mlp[3].bias, cx, resid=x1, keep=keep2)
     if save is not None:
         save.append(("block", blk, pre, (x, m1, r1, ln1p, qkv, att, x1, m2, r2, ln2, hpre, hact, keep1, keep2,
                                           (H, W, He, We))))
     return x2
 
 
-def _block_bwd(blk, pre, ctx, dx2, dt, grads):
+def _block_bwd(blk, pre, ctx, dx2, cx, grads):
     x, m1, r1, ln1p, qkv, att, x1, m2, r2, ln2, hpre, hact, keep1, keep2, (H, W, He, We) = ctx
     a = blk.attn
     padded = (He, We) != (H, W)
     # MLP branch
     db = ops.scale_sample(dx2, keep2) if keep2 is not None else dx2
-    dh = _linear_bwd(hact, db, blk.mlp[3].weight, dt, grads, pre + "mlp.3.weight", pre + "mlp.3.bias")
+    dh = _linear_bwd(hact, db, blk.mlp[3].weight, cx, grads, pre + "mlp.3.weight", pre + "mlp.3.bias")
     dhp = ops.gelu_bwd(dh, hpre)
-    dln2 = _linear_bwd(ln2, dhp, blk.mlp[0].weight, dt, grads, pre + "mlp.0.weight", pre + "mlp.0.bias")
+    dln2 = _linear_bwd(ln2, dhp, blk.mlp[0].weight, cx, grads, pre + "mlp.0.weight", pre + "mlp.0.bias")
     dx1, grads[pre + "norm2.weight"], grads[pre + "norm2.bias"] = ops.layernorm_bwd(
         dln2, x1, blk.norm2.weight, m2, r2, add=dx2)
     # attention branch
     db = ops.scale_sample(dx1, keep1) if keep1 is not None else dx1
     dbp = _pad_tokens(db, He, We) if padded else db
-    datt = _linear_bwd(att, dbp, a.proj.weight, dt, grads, pre + "attn.proj.weight", pre + "attn.proj.bias")
+    datt = _linear_bwd(att, dbp, a.proj.weight, cx, grads, pre + "attn.proj.weight", pre + "attn.proj.bias")
     dqkv, grads[pre + "attn.relative_position_bias_table"] = ops.window_attn_bwd(
         qkv, datt, a.relative_position_bias_table, a.num_heads, blk.shift_size, True)
-    dln1 = _linear_bwd(ln1p, dqkv, a.qkv.weight, dt, grads, pre + "attn.qkv.weight", pre + "attn.qkv.bias")
+    dln1 = _linear_bwd(ln1p, dqkv, a.qkv.weight, cx, grads, pre + "attn.qkv.weight", pre + "attn.qkv.bias")
     if padded:
         dln1 = dln1[:, :H, :W].contiguous()
     dx, grads[pre + "norm1.weight"], grads[pre + "norm1.bias"] = ops.layernorm_bwd(
@@ -315,9 +324,9 @@ def _block_bwd(blk, pre, ctx, dx2, dt, grads):
     return dx
 
 
-def _conv_bn_relu_fwd(conv, bn, t, dt, training, save, tag):
+def _conv_bn_relu_fwd(conv, bn, t, cx, training, save, tag):
     """Conv3x3 -> BatchNorm2d -> ReLU.  A conv bias in front of BatchNorm only moves running_mean."""
-    pk = _packed(conv.weight, dt)
+    pk = cx.packed(conv.weight)
     if not training:
         sc, sh = ops.bn_fold_eval(bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.bias, bn.eps)
         return ops.conv_fwd(t, pk, scale=sc, shift=sh, act=1)[0]
@@ -334,7 +343,7 @@ def _conv_bn_relu_fwd(conv, bn, t, dt, training, save, tag):
     return a
 
 
-def _conv_bn_relu_bwd(conv, bn, tag, ctx, g, dt, grads, need_dx=True):
+def _conv_bn_relu_bwd(conv, bn, tag, ctx, g, cx, grads, need_dx=True):
     t, y, mean, invstd, sc, sh = ctx
     dy, dgamma, dbeta = ops.bn_act_bwd(g, y, sc, sh, mean, invstd, None, relu=True)
     cname, bname = tag
@@ -343,46 +352,46 @@ def _conv_bn_relu_bwd(conv, bn, tag, ctx, g, dt, grads, need_dx=True):
     if conv.bias is not None:
         grads[cname + ".bias"] = torch.zeros_like(conv.bias)      # exactly 0 in front of BatchNorm
     if need_dx:
-        return ops.conv_fwd(dy, _packed(conv.weight, dt, transpose=True))[0]
+        return ops.conv_fwd(dy, cx.packed(conv.weight, transpose=True))[0]
     return None
 
 
-def _decoder_fwd(dec, pre, x, skip, dt, training, save):
+def _decoder_fwd(dec, pre, x, skip, cx, training, save):
     """DecoderBlock (:520-535): ConvTranspose(2,2)+bias, 1x1 skip projection, concat, DoubleConv."""
     B, h, w, Cin = x.shape
     up = dec.upsample.out_channels
     has_skip = skip is not None and dec.skip_projection is not None
-    cat = torch.empty((B, 2 * h, 2 * w, up * (2 if has_skip else 1)), dtype=dt, device=x.device)
+    cat = torch.empty((B, 2 * h, 2 * w, up * (2 if has_skip else 1)), dtype=cx.dt, device=x.device)
     w2 = dec.upsample.weight.permute(2, 3, 1, 0).reshape(4 * up, Cin)       # [(ky,kx,co)][ci]
-    tmp = _linear(x, w2, None, dt)
+    tmp = _linear(x, w2, None, cx)
     ops.pixel_shuffle(tmp, cat, dec.upsample.bias, up)
     resized = None
     if has_skip:
         if skip.shape[1:3] == (2 * h, 2 * w):
-            ops.conv_fwd(skip, _packed(dec.skip_projection.weight, dt), out=cat[..., up:])
+            ops.conv_fwd(skip, cx.packed(dec.skip_projection.weight), out=cat[..., up:])
         else:       # bilinear resize of the projected skip to the upsampled size (:526-529)
-            sp = _linear(skip, dec.skip_projection.weight.view(up, -1), None, dt)
+            sp = _linear(skip, dec.skip_projection.weight.view(up, -1), None, cx)
             resized = sp.shape[1:3]
-            cat[..., up:] = ops.upsample_concat(sp, torch.empty((B, 2 * h, 2 * w, 0), dtype=dt, device=x.device))
+            cat[..., up:] = ops.upsample_concat(sp, torch.empty((B, 2 * h, 2 * w, 0), dtype=cx.dt, device=x.device))
     if save is not None:
         save.append(("dec_head", dec, pre, (x, skip, w2, resized)))
-    t = _conv_bn_relu_fwd(dec.conv_block[0], dec.conv_block[1], cat, dt, training, save,
+    t = _conv_bn_relu_fwd(dec.conv_block[0], dec.conv_block[1], cat, cx, training, save,
                           (pre + "conv_block.0", pre + "conv_block.1"))
-    return _conv_bn_relu_fwd(dec.conv_block[3], dec.conv_block[4], t, dt, training, save,
+    return _conv_bn_relu_fwd(dec.conv_block[3], dec.conv_block[4], t, cx, training, save,
                              (pre + "conv_block.3", pre + "conv_block.4"))
 
 
-def _decoder_head_bwd(dec, pre, ctx, dcat, dt, grads):
+def _decoder_head_bwd(dec, pre, ctx, dcat, cx, grads):
     """Returns (dx, dskip or None)."""
     x, skip, w2, resized = ctx
     B, h, w, Cin = x.shape
     up = dec.upsample.out_channels
-    dtmp = torch.empty((B, h, w, 4 * up), dtype=dt, device=x.device)
+    dtmp = torch.empty((B, h, w, 4 * up), dtype=cx.dt, device=x.device)
     ops.pixel_shuffle(dtmp, dcat, None, up, backward=True)
     grads[pre + "upsample.bias"] = ops.channel_sum(dcat, up)
     dw2 = ops.conv_wgrad(x, dtmp, Cin, 4 * up, 1).view(2, 2, up, Cin)
     grads[pre + "upsample.weight"] = dw2.permute(3, 2, 0, 1).contiguous()
-    dx = ops.conv_fwd(dtmp, ops.PackedConv(w2.contiguous(), dt, transpose=True))[0]
+    dx = _linear_launch(dtmp, ops.PackedConv(w2.contiguous(), cx.dt, transpose=True))
     dskip = None
     if skip is not None and dec.skip_projection is not None:
         wsk = dec.skip_projection.weight
@@ -390,22 +399,22 @@ def _decoder_head_bwd(dec, pre, ctx, dcat, dt, grads):
         if resized is not None:
             dsp = ops.upsample_bwd(dsp.contiguous(), up, resized[0], resized[1])
         grads[pre + "skip_projection.weight"] = ops.conv_wgrad(skip, dsp, wsk.shape[1], up, 1).view(wsk.shape)
-        dskip = ops.conv_fwd(dsp, _packed(wsk, dt, transpose=True))[0]
+        dskip = ops.conv_fwd(dsp, cx.packed(wsk, transpose=True))[0]
     return dx, dskip
 
 
 def _forward(model, x, drop_path, save):
     """Whole network.  save=None: inference (BatchNorm folded, nothing kept)."""
-    dt = model.compute_dtype
     training = save is not None
-    pool = _prepack(model, dt, training)
+    cx = _Ctx(model, training)
+    dt = cx.dt
     if training:
-        save.append(("packs", pool))
+        save.append(("packs", cx))
     ps = model.patch_size_val
     E = model.embed_dim_val
     tok_in = ops.patchify(x.detach(), ps, dt)
     wpe = model.patch_embed.weight.reshape(E, -1)
-    t0 = _linear(tok_in, wpe, model.patch_embed.bias, dt)
+    t0 = _linear(tok_in, wpe, model.patch_embed.bias, cx)
     t, m0, r0 = ops.layernorm_fwd(t0, model.norm_embed.weight, model.norm_embed.bias, model.norm_embed.eps)
     if training:
         save.append(("embed", (tok_in, t0, m0, r0)))
@@ -414,14 +423,14 @@ def _forward(model, x, drop_path, save):
     for li, layer in enumerate(model.layers):
         for bi, blk in enumerate(layer.blocks):
             k1, k2 = drop_path[bno] if (training and drop_path is not None) else (None, None)
-            t = _block_fwd(blk, f"layers.{li}.blocks.{bi}.", t, k1, k2, dt, save)
+            t = _block_fwd(blk, f"layers.{li}.blocks.{bi}.", t, k1, k2, cx, save)
             bno += 1
         skips.append(t)
         if layer.downsample is not None:
             ds = layer.downsample
             mg = ops.merge_gather(t)
             ln, mm, rr = ops.layernorm_fwd(mg, ds.norm.weight, ds.norm.bias, ds.norm.eps)
-            nxt = _linear(ln, ds.reduction.weight, None, dt)
+            nxt = _linear(ln, ds.reduction.weight, None, cx)
             if training:
                 save.append(("merge", ds, f"layers.{li}.downsample.", li, (t.shape, mg, mm, rr, ln)))
             t = nxt
@@ -429,11 +438,11 @@ def _forward(model, x, drop_path, save):
     nl = model.num_layers
     for i, dec in enumerate(model.decoders):
         si = nl - 2 - i
-        d = _decoder_fwd(dec, f"decoders.{i}.", d, skips[si] if si >= 0 else None, dt, training, save)
+        d = _decoder_fwd(dec, f"decoders.{i}.", d, skips[si] if si >= 0 else None, cx, training, save)
         if training:
             save.append(("dec_tail", i, si))
     fc = model.final_conv
-    f = _conv_bn_relu_fwd(fc[0], fc[1], d, dt, training, save, ("final_conv.0", "final_conv.1"))
+    f = _conv_bn_relu_fwd(fc[0], fc[1], d, cx, training, save, ("final_conv.0", "final_conv.1"))
     out = ops.head1x1_fwd(f, fc[3].weight, fc[3].bias)
     if training:
         save.append(("head", f))
@@ -452,14 +461,15 @@ class _SwinTrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         model, save = ctx.model, ctx.save
-        dt = model.compute_dtype
-        grads: Dict[str, torch.Tensor] = {}
+        if save is None:
+            raise RuntimeError("the SwinUNet step was already back-propagated: its saved activations are freed "
+                               "by the first backward (run the forward again)")
+        cx = save[0][1]                 # dtype and the packs made by this step's forward
+        grads = ops.GradOut(model.grad_sink)
         nl = model.num_layers
         dskips: Dict[int, torch.Tensor] = {}
         g = None
         pending_skip = None
-        global _POOL
-        _POOL = save[0][1]              # the packs made by this step's forward
         for rec in reversed(save):
             kind = rec[0]
             if kind == "packs":
@@ -470,18 +480,18 @@ class _SwinTrainFn(torch.autograd.Function):
                 grads["final_conv.3.weight"], grads["final_conv.3.bias"] = dw, db
             elif kind == "cbr":
                 _, conv, bn, tag, c = rec
-                g = _conv_bn_relu_bwd(conv, bn, tag, c, g, dt, grads)
+                g = _conv_bn_relu_bwd(conv, bn, tag, c, g, cx, grads)
             elif kind == "dec_tail":
                 pass
             elif kind == "dec_head":
                 _, dec, pre, c = rec
                 i = int(pre.split(".")[1])
-                g, dsk = _decoder_head_bwd(dec, pre, c, g, dt, grads)
+                g, dsk = _decoder_head_bwd(dec, pre, c, g, cx, grads)
                 if dsk is not None:
                     dskips[nl - 2 - i] = dsk
             elif kind == "merge":
                 _, ds, pre, li, (shape, mg, mm, rr, ln) = rec
-                dln = _linear_bwd(ln, g, ds.reduction.weight, dt, grads, pre + "reduction.weight", None)
+                dln = _linear_bwd(ln, g, ds.reduction.weight, cx, grads, pre + "reduction.weight", None)
                 dmg, grads[pre + "norm.weight"], grads[pre + "norm.bias"] = ops.layernorm_bwd(
                     dln, mg, ds.norm.weight, mm, rr)
                 g = ops.merge_scatter(dmg, shape[1], shape[2])
@@ -489,7 +499,7 @@ class _SwinTrainFn(torch.autograd.Function):
                     g = ops.scale_sample(g, None, dskips.pop(li))
             elif kind == "block":
                 _, blk, pre, c = rec
-                g = _block_bwd(blk, pre, c, g, dt, grads)
+                g = _block_bwd(blk, pre, c, g, cx, grads)
             elif kind == "embed":
                 tok_in, t0, m0, r0 = rec[1]
                 E = model.embed_dim_val
@@ -501,7 +511,7 @@ class _SwinTrainFn(torch.autograd.Function):
                 grads["patch_embed.bias"] = ops.channel_sum(dt0, E)
                 g = None
                 if ctx.need_dx:
-                    dtok = ops.conv_fwd(dt0, _packed(wpe, dt, transpose=True))[0]
+                    dtok = ops.conv_fwd(dt0, cx.packed(wpe, transpose=True))[0]
                     B, Cin, H, W = ctx.in_shape
                     g = ops.unpatchify(dtok, Cin, H, W, model.patch_size_val)
         ctx.save = None

@@ -45,6 +45,9 @@ class OptimizedUNet(nn.Module):
         self._initialize_weights()
         # test hook: a list of nine (B, C) keep masks (0 or 1/(1-p)) used instead of fresh draws
         self.dropout_masks_override: Optional[List[torch.Tensor]] = None
+        # data-parallel hook: callable (name, grad) -> grad that receives every parameter gradient as
+        # soon as the backward pass has queued its kernel (unet_amd.dist.GradReducer installs itself)
+        self.grad_sink = None
 
     @staticmethod
     def _block(cin, cout):
@@ -245,6 +248,7 @@ class _UNetTrainFn(torch.autograd.Function):
         out = ops.head1x1_fwd(d, model.conv.weight, model.conv.bias)
         ctx.model = model
         ctx.saved = saved
+        ctx.versions = [p._version for p in params]
         ctx.need_dx = ctx.needs_input_grad[0]
         ctx.in_shape = x.shape
         return out
@@ -252,15 +256,21 @@ class _UNetTrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         model, saved = ctx.model, ctx.saved
+        if saved is None:
+            raise RuntimeError("the UNet step was already back-propagated: its saved activations are freed by "
+                               "the first backward (run the forward again)")
+        if ctx.versions != [p._version for p in model.parameters()]:
+            raise RuntimeError("a UNet parameter was modified in place between the forward pass and its backward "
+                               "pass (the packed copies made by the forward no longer match)")
         dt = model.compute_dtype
         pkT = ctx.pkT
         ctx.pkT = None
-        grads = {}
+        grads = ops.GradOut(model.grad_sink)
         # Weight gradients are off the critical chain (dgrad -> BatchNorm backward -> dgrad ...):
         # optionally they run on a second HIP stream, overlapping the HBM-bound BatchNorm / pool /
         # resize backward passes of the following layers.
         main = torch.cuda.current_stream()
-        side = _side_stream(dout.device) if OVERLAP_WGRAD else main
+        side = _side_stream(dout.device) if (OVERLAP_WGRAD and model.grad_sink is None) else main
         held = []          # operands of side-stream kernels stay allocated until the join
 
         # final 1x1 conv
