@@ -166,8 +166,9 @@ def test_train_forward_backward_bf16(golden, name):
 
 def test_bf16_loss_curve_tracks_fp32():
     """The regime that matters: a learnable target (a fixed smooth function of the input), 20 optimiser
-    steps from the same initialisation in fp32 and in bf16 storage.  The two loss curves must agree within
-    5 % at every step and both must learn (final loss below 60 % of the first)."""
+    steps from the same initialisation in fp32 and in bf16 storage, while the loss falls by a factor of ~40.
+    The two loss curves must agree within 10 % at every step and within 4 % on average, and both must learn
+    (final loss below a tenth of the first)."""
     from unet_amd import OptimizedUNet
     from unet_amd.optim import FusedAdamW
     torch.manual_seed(7)
@@ -196,8 +197,8 @@ def test_bf16_loss_curve_tracks_fp32():
     dev = np.abs(b16 - f32) / f32
     print("fp32 loss curve", np.round(f32, 4).tolist())
     print("bf16 loss curve", np.round(b16, 4).tolist(), "max deviation", dev.max())
-    assert f32[-1] < 0.6 * f32[0] and b16[-1] < 0.6 * b16[0]
-    assert dev.max() < 5e-2, dev
+    assert f32[-1] < 0.1 * f32[0] and b16[-1] < 0.1 * b16[0]
+    assert dev.max() < 0.10 and dev.mean() < 0.04, dev
 
 
 def test_config2_full_size_properties(golden):
