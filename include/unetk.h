@@ -91,6 +91,20 @@ int unetk_linear_wgrad(const void* in, int ldin, const void* dy, int lddy, float
                        int Ci, int Co, int dtype, void* workspace, int64_t workspace_bytes, int accumulate,
                        unetk_stream_t stream);
 
+/* nn.Linear over tokens, forward and data gradient (swin_unet_model.py:234, 236, 298-301, 383, 501, 506):
+ *   out[t][n] = epilogue(sum_k x[t][k] * w[n][k]),  t < M, with w packed as for unetk_conv_fwd (ks = 1,
+ *   channel block bn; transpose = 1 for the data gradient).  bfloat16 only: unetk_linear_supported says
+ *   whether a shape can take this path (else use unetk_conv_fwd with ks = 1).
+ * Epilogue, every part optional: + bias[n]; act = UNETK_ACT_GELU, with out2 given the pre-activation goes
+ * to out and GELU(pre-activation) to out2 (the MLP's hidden layer, :298-299); gelu_grad_of: the result is
+ * multiplied by GELU'(gelu_grad_of[t][n]) (data gradient through that GELU); resid (+ resid_keep per
+ * sample of tok_per_sample tokens): out = resid + resid_keep[t / tok_per_sample] * value (:371-372). */
+int unetk_linear_supported(int64_t M, int K, int N, int bn, int dtype);
+int unetk_linear_fwd(const void* x, int ldx, const void* wpacked, void* out, int ldo, void* out2, int ldo2,
+                     int64_t M, int K, int N, int bn, int dtype, const float* bias, int act, const void* resid,
+                     int ldr, const float* resid_keep, int64_t tok_per_sample, const void* gelu_grad_of, int ldaux,
+                     unetk_stream_t stream);
+
 /* ---- layout ------------------------------------------------------------------------ */
 int unetk_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int ld, int dtype,
                        unetk_stream_t stream);

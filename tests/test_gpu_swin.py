@@ -128,6 +128,46 @@ def test_window_attention_fwd_bwd(dt, case):
     assert rel(dtable, tr_.grad) < TOL[dt] * (2 if dt == torch.bfloat16 else 1)
 
 
+@pytest.mark.parametrize("shape", [(2, 5, 7, 96, 288), (1, 16, 16, 384, 96), (3, 8, 8, 192, 768), (1, 8, 8, 768, 2304),
+                                   (2, 9, 4, 64, 96), (1, 24, 24, 1536, 384), (2, 16, 8, 512, 1024), (1, 4, 4, 96, 32)])
+def test_token_linear_gemm(shape):
+    """The bfloat16 token-linear GEMM kernel against torch on exactly representable inputs: plain, bias,
+    GELU with the pre-activation as second output, GELU' multiplier (data gradient of the MLP), residual with a
+    per-sample scale, output into a channel slice of a wider buffer, token counts that are not tile multiples."""
+    from unet_amd import ops
+    B, H, Wd, K, N = shape
+    dt = torch.bfloat16
+    x = rnd((B, H, Wd, K), 21, dt, 0.7)
+    w = rnd((N, K), 22, dt, 1.0 / K ** 0.5)
+    b = rnd((N,), 23, torch.float32, 0.3)
+    xd, bd = x.to("cuda", dt), b.cuda()
+    pw = ops.PackedConv(w.cuda(), dt)
+    assert ops.linear_supported(xd, pw)
+    ref = F.linear(x.double(), w.double())
+    assert rel(ops.linear_fwd(xd, pw), ref) < 1e-2
+    refb = ref + b.double()
+    pre, act = ops.linear_fwd(xd, pw, bias=bd, act=2, out2=True)
+    assert rel(pre, refb) < 1e-2
+    assert rel(act, F.gelu(pre.double().cpu())) < 1e-2
+    assert rel(ops.linear_fwd(xd, pw, bias=bd, act=2), F.gelu(refb)) < 1e-2
+    h = rnd((B, H, Wd, N), 24, dt, 1.5)
+    hr = h.double().requires_grad_(True)
+    F.gelu(hr).backward(ref)
+    assert rel(ops.linear_fwd(xd, pw, gelu_grad_of=h.to("cuda", dt)), hr.grad) < 1e-2
+    res = rnd((B, H, Wd, N), 25, dt)
+    keep = torch.tensor([0.0, 1.25, 1.0][:B])
+    got = ops.linear_fwd(xd, pw, bias=bd, resid=res.to("cuda", dt), resid_keep=keep.cuda())
+    assert rel(got, res.double() + keep.view(B, 1, 1, 1).double() * refb) < 1e-2
+    wide = torch.full((B, H, Wd, N + 64), 7.0, dtype=dt, device="cuda")
+    ops.linear_fwd(xd, pw, out=wide[..., 64:])
+    assert rel(wide[..., 64:], ref) < 1e-2 and torch.all(wide[..., :64] == 7.0)
+    # the data-gradient form: transposed pack
+    pwt = ops.PackedConv(w.cuda(), dt, transpose=True)
+    dy = rnd((B, H, Wd, N), 26, dt)
+    if ops.linear_supported(dy.to("cuda", dt), pwt):
+        assert rel(ops.linear_fwd(dy.to("cuda", dt), pwt), dy.double() @ w.double()) < 1e-2
+
+
 def build(dt):
     from unet_amd.swin import SwinUNet
     cfg = dict(swin_oracle.DEFAULT_CONFIG)

@@ -43,6 +43,8 @@ _SIGNATURES = {
     "unetk_conv_wgrad": (I, [P, I, P, I, P, I, I, I, I, I, I, I, P, L, I, P]),
     "unetk_linear_wgrad_workspace_bytes": (L, [L, I, I, I]),
     "unetk_linear_wgrad": (I, [P, I, P, I, P, P, L, I, I, I, P, L, I, P]),
+    "unetk_linear_supported": (I, [L, I, I, I, I]),
+    "unetk_linear_fwd": (I, [P, I, P, P, I, P, I, L, I, I, I, I, P, I, P, I, P, L, P, I, P]),
     "unetk_optim_chunk_elems": (I, []),
     "unetk_grad_norm": (I, [P, P, P, I, F, P, P, P]),
     "unetk_scale_list": (I, [P, P, P, I, P, P]),

@@ -205,6 +205,37 @@ def conv_fwd(x: torch.Tensor, pw: PackedConv, Ci: Optional[int] = None, Co: Opti
     return out, stats
 
 
+def linear_supported(x: torch.Tensor, pw: PackedConv) -> bool:
+    """Whether the token-linear GEMM kernel takes this product (bfloat16, K a multiple of 32, N a multiple of the
+    packed channel block); everything else goes through the 1x1 form of the convolution kernel."""
+    if pw.ks != 1 or x.dtype != torch.bfloat16 or x.shape[-1] != pw.Ci or x.stride(-1) != 1:
+        return False
+    M = x.numel() // x.shape[-1]
+    return bool(_lib.load().unetk_linear_supported(M, pw.Ci, pw.Co, pw.bn, dtype_code(x.dtype)))
+
+
+def linear_fwd(x, pw: PackedConv, bias=None, act=0, resid=None, resid_keep=None, out=None, out2=False,
+               gelu_grad_of=None):
+    """out[..., n] = epilogue(sum_k x[..., k] * w[n][k]) for a channels-last token tensor x (..., K) whose token rows
+    are equally spaced (a dense tensor or a channel slice of one).  ``out`` may be a channel slice of a wider dense
+    buffer.  ``out2=True`` (with GELU): returns (pre-activation, GELU(pre-activation)).  ``gelu_grad_of``: the
+    result is multiplied by GELU'(that tensor).  ``resid``/``resid_keep``: resid + keep[sample] * value."""
+    K, N = pw.Ci, pw.Co
+    M = x.numel() // x.shape[-1]
+    ldx = x.stride(-2)
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
+    second = torch.empty_like(out) if out2 else None
+    tps = 1
+    if resid_keep is not None:
+        tps = M // x.shape[0]
+    call("unetk_linear_fwd", ptr(x), ldx, ptr(pw.data), ptr(out), out.stride(-2), ptr(second),
+         second.stride(-2) if second is not None else 0, M, K, N, pw.bn, dtype_code(x.dtype), ptr(bias), act,
+         ptr(resid), resid.stride(-2) if resid is not None else 0, ptr(resid_keep), tps, ptr(gelu_grad_of),
+         gelu_grad_of.stride(-2) if gelu_grad_of is not None else 0, stream())
+    return (out, second) if out2 else out
+
+
 def linear_wgrad(x: torch.Tensor, dy: torch.Tensor, Ci: int, Co: int):
     """(dw (Co,Ci), db (Co,)) fp32 of a linear layer over tokens: x (..., ldx) and dy (..., lddy) channels-last.
     bfloat16 with unpadded channel counts: one pass over dy gives both; otherwise conv_wgrad + channel_sum."""

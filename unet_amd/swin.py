@@ -234,17 +234,28 @@ class _Ctx:
         return ops.PackedConv(w, self.dt, transpose=transpose)
 
 
-def _linear_launch(x, pw, **kw):
-    """Every token-linear GEMM launch (forward and data gradient) goes through here."""
-    return ops.conv_fwd(x, pw, **kw)[0]
+def _linear_launch(x, pw, shift=None, act=0, resid=None, resid_keep=None, out=None, out2=False, gelu_grad_of=None):
+    """Every token-linear GEMM launch (forward and data gradient) goes through here: the GEMM kernel
+    where it applies (bfloat16, regular shapes), else the 1x1 form of the convolution kernel with the
+    GELU passes as separate launches."""
+    if ops.linear_supported(x, pw):
+        return ops.linear_fwd(x, pw, bias=shift, act=act, resid=resid, resid_keep=resid_keep, out=out, out2=out2,
+                              gelu_grad_of=gelu_grad_of)
+    if out2:        # (pre-activation, activation)
+        pre = ops.conv_fwd(x, pw, scale=None, shift=shift, act=0, out=out)[0]
+        return pre, ops.gelu_fwd(pre)
+    y = ops.conv_fwd(x, pw, scale=None, shift=shift, act=act, resid=resid, resid_keep=resid_keep, out=out)[0]
+    if gelu_grad_of is not None:
+        y = ops.gelu_bwd(y, gelu_grad_of)
+    return y
 
 
 # ------------------------------------------------------------------ building blocks
-def _linear(x, w, b, cx, act=0, resid=None, keep=None, out=None):
-    return _linear_launch(x, cx.packed(w), scale=None, shift=b, act=act, resid=resid, resid_keep=keep, out=out)
+def _linear(x, w, b, cx, act=0, resid=None, keep=None, out=None, out2=False):
+    return _linear_launch(x, cx.packed(w), shift=b, act=act, resid=resid, resid_keep=keep, out=out, out2=out2)
 
 
-def _linear_bwd(x, dy, w, cx, grads, wname, bname, need_dx=True):
+def _linear_bwd(x, dy, w, cx, grads, wname, bname, need_dx=True, gelu_grad_of=None):
     Co, Ci = w.shape[0], w.shape[1]
     if bname is not None:
         dw, grads[bname] = ops.linear_wgrad(x, dy, Ci, Co)
@@ -252,7 +263,7 @@ def _linear_bwd(x, dy, w, cx, grads, wname, bname, need_dx=True):
     else:
         grads[wname] = ops.conv_wgrad(x, dy, Ci, Co, 1).view(w.shape)
     if need_dx:
-        return _linear_launch(dy, cx.packed(w.view(Co, Ci), transpose=True))
+        return _linear_launch(dy, cx.packed(w.view(Co, Ci), transpose=True), gelu_grad_of=gelu_grad_of)
     return None
 
 
@@ -290,8 +301,7 @@ def _block_fwd(blk, pre, x, keep1, keep2, cx, save):
         pr = _linear(att, a.proj.weight, a.proj.bias, cx)
         x1 = ops.scale_sample(pr[:, :H, :W].contiguous(), keep1, x)
     ln2, m2, r2 = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
-    hpre = _linear(ln2, blk.mlp[0].weight, blk.mlp[0].bias, cx)
-    hact = ops.gelu_fwd(hpre)
+    hpre, hact = _linear(ln2, blk.mlp[0].weight, blk.mlp[0].bias, cx, act=2, out2=True)
     x2 = _linear(hact, blk.mlp[3].weight, blk.mlp[3].bias, cx, resid=x1, keep=keep2)
     if save is not None:
         save.append(("block", blk, pre, (x, m1, r1, ln1p, qkv, att, x1, m2, r2, ln2, hpre, hact, keep1, keep2,
@@ -305,8 +315,8 @@ def _block_bwd(blk, pre, ctx, dx2, cx, grads):
     padded = (He, We) != (H, W)
     # MLP branch
     db = ops.scale_sample(dx2, keep2) if keep2 is not None else dx2
-    dh = _linear_bwd(hact, db, blk.mlp[3].weight, cx, grads, pre + "mlp.3.weight", pre + "mlp.3.bias")
-    dhp = ops.gelu_bwd(dh, hpre)
+    dhp = _linear_bwd(hact, db, blk.mlp[3].weight, cx, grads, pre + "mlp.3.weight", pre + "mlp.3.bias",
+                      gelu_grad_of=hpre)
     dln2 = _linear_bwd(ln2, dhp, blk.mlp[0].weight, cx, grads, pre + "mlp.0.weight", pre + "mlp.0.bias")
     dx1, grads[pre + "norm2.weight"], grads[pre + "norm2.bias"] = ops.layernorm_bwd(
         dln2, x1, blk.norm2.weight, m2, r2, add=dx2)
@@ -368,7 +378,7 @@ def _decoder_fwd(dec, pre, x, skip, cx, training, save):
     resized = None
     if has_skip:
         if skip.shape[1:3] == (2 * h, 2 * w):
-            ops.conv_fwd(skip, cx.packed(dec.skip_projection.weight), out=cat[..., up:])
+            _linear_launch(skip, cx.packed(dec.skip_projection.weight), out=cat[..., up:])
         else:       # bilinear resize of the projected skip to the upsampled size (:526-529)
             sp = _linear(skip, dec.skip_projection.weight.view(up, -1), None, cx)
             resized = sp.shape[1:3]
@@ -399,7 +409,7 @@ def _decoder_head_bwd(dec, pre, ctx, dcat, cx, grads):
         if resized is not None:
             dsp = ops.upsample_bwd(dsp.contiguous(), up, resized[0], resized[1])
         grads[pre + "skip_projection.weight"] = ops.conv_wgrad(skip, dsp, wsk.shape[1], up, 1).view(wsk.shape)
-        dskip = ops.conv_fwd(dsp, cx.packed(wsk, transpose=True))[0]
+        dskip = _linear_launch(dsp, cx.packed(wsk, transpose=True))
     return dx, dskip
 
 
@@ -511,7 +521,7 @@ class _SwinTrainFn(torch.autograd.Function):
                 grads["patch_embed.bias"] = ops.channel_sum(dt0, E)
                 g = None
                 if ctx.need_dx:
-                    dtok = ops.conv_fwd(dt0, cx.packed(wpe, transpose=True))[0]
+                    dtok = _linear_launch(dt0, cx.packed(wpe, transpose=True))
                     B, Cin, H, W = ctx.in_shape
                     g = ops.unpatchify(dtok, Cin, H, W, model.patch_size_val)
         ctx.save = None
