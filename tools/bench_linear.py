@@ -30,12 +30,14 @@ for side, C in ((64, 96), (32, 192), (16, 384), (8, 768)):
         td = timeit(lambda: ops.conv_fwd(dy, pwt))
         gf = timeit(lambda: ops.linear_fwd(x, pw)) if ops.linear_supported(x, pw) else float("nan")
         gd = timeit(lambda: ops.linear_fwd(dy, pwt)) if ops.linear_supported(dy, pwt) else float("nan")
+        gg = timeit(lambda: ops.linear_fwd(x, pw, act=2, out2=True)) if ops.linear_supported(x, pw) else float("nan")
+        ga = timeit(lambda: ops.linear_fwd(dy, pwt, gelu_grad_of=x)) if ops.linear_supported(dy, pwt) else float("nan")
         tot[3] += gf; tot[4] += gd
         tw = timeit(lambda: ops.conv_wgrad(x, dy, ci, co, 1, workspace=ws))
         M = B * side * side
         fl = 2.0 * M * ci * co
         by = 2.0 * M * (ci + co)
         tot[0] += tf; tot[1] += td; tot[2] += tw
-        print(f"{side:3d}^2 {name:5s} {ci:5d}->{co:5d}  GEMM fwd {gf*1e3:6.1f} us {fl/gf/1e9:5.0f} TF/s {by/gf/1e9:5.2f} TB/s dgrad {gd*1e3:6.1f} us {fl/gd/1e9:5.0f} TF/s || conv1x1 fwd {tf*1e3:7.1f} us {fl/tf/1e9:6.0f} TF/s {by/tf/1e9:5.2f} TB/s | "
+        print(f"{side:3d}^2 {name:5s} {ci:5d}->{co:5d}  GEMM fwd {gf*1e3:6.1f} us {fl/gf/1e9:5.0f} TF/s {by/gf/1e9:5.2f} TB/s dgrad {gd*1e3:6.1f} | gelu2 {gg*1e3:6.1f} gelu' {ga*1e3:6.1f} || conv1x1 fwd {tf*1e3:7.1f} us {fl/tf/1e9:6.0f} TF/s {by/tf/1e9:5.2f} TB/s | "
               f"dgrad {td*1e3:7.1f} us {fl/td/1e9:6.0f} TF/s | wgrad {tw*1e3:7.1f} us {fl/tw/1e9:6.0f} TF/s {by/tw/1e9:5.2f} TB/s", flush=True)
 print("sum ms", [round(t, 3) for t in tot])

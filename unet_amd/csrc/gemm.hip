@@ -65,10 +65,29 @@ __device__ __forceinline__ void wait_vm_barrier_g(int n) {
 #undef UNETK_WVB
 }
 
-__device__ __forceinline__ float gelu_erf_g(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+// GELU (erf form) and its derivative for the bf16 epilogues.  Phi(v) = 0.5 * (1 + erf(v / sqrt 2)) through
+// Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the 2^-9 rounding of the bf16 result): one
+// reciprocal, one exponential and five multiply-adds, against the several dozen instructions and
+// branches of the library erff.  The exponential exp(-v^2 / 2) is also the Gaussian of the derivative.
+struct PhiExp {
+  float Phi, e;     // Phi(v), exp(-v*v/2)
+};
+__device__ __forceinline__ PhiExp phi_exp(float v) {
+  const float z = fabsf(v) * 0.70710678118654752440f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float e = __expf(-z * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.0f - poly * e;
+  PhiExp r;
+  r.Phi = 0.5f * (1.0f + (v < 0.f ? -erf_abs : erf_abs));
+  r.e = e;
+  return r;
+}
+__device__ __forceinline__ float gelu_erf_g(float v) { return v * phi_exp(v).Phi; }
 // d/dv [ v * Phi(v) ] = Phi(v) + v * phi(v)
 __device__ __forceinline__ float gelu_grad_g(float v) {
-  return 0.5f * (1.0f + erff(v * 0.70710678118654752440f)) + v * 0.3989422804014327f * __expf(-0.5f * v * v);
+  const PhiExp p = phi_exp(v);
+  return p.Phi + v * 0.3989422804014327f * p.e;
 }
 
 template <int TM, int TN>
@@ -264,12 +283,12 @@ int unetk_linear_fwd(const void* x, int ldx, const void* wpacked, void* out, int
   a.ldx = ldx; a.ldo = ldo; a.ldo2 = ldo2; a.ldr = ldr; a.ldaux = ldaux;
   a.M = (int)M; a.N = N; a.K = K; a.nchunks = K / 32; a.act = act;
   a.tok_per_sample = resid_keep ? (int)tok_per_sample : 1;
-  // 128-token tiles (three workgroups per CU) unless the problem fills the chip several times over
-  // with 256-token tiles and is deep enough in K for their better MFMA : LDS-read ratio to matter
-  const bool big = K >= 384 && cdiv(M, 256) * (N / bn) >= 1024;
+  // 128-token tiles, three workgroups per CU.  (256-token tiles, two per CU, measured slower on every
+  // Swin shape, 64x64 tokens x 96 channels to 8x8 tokens x 3072 channels: these products are bound by
+  // bytes and by how many workgroups cover each other's waits, not by the MFMA : LDS-read ratio.)
   switch (bn) {
-    case 96: return big ? launch_gemm<4, 6>(a, stream) : launch_gemm<2, 6>(a, stream);
-    case 64: return big ? launch_gemm<4, 4>(a, stream) : launch_gemm<2, 4>(a, stream);
+    case 96: return launch_gemm<2, 6>(a, stream);
+    case 64: return launch_gemm<2, 4>(a, stream);
     default: return launch_gemm<2, 2>(a, stream);
   }
 }

@@ -18,6 +18,7 @@ import torch.nn as nn
 from . import ops
 
 _WS = 8
+_FUSE_GELU_BWD_ELEMS = 1 << 25
 
 
 # ------------------------------------------------------------------ parameter containers
@@ -301,7 +302,9 @@ def _block_fwd(blk, pre, x, keep1, keep2, cx, save):
         pr = _linear(att, a.proj.weight, a.proj.bias, cx)
         x1 = ops.scale_sample(pr[:, :H, :W].contiguous(), keep1, x)
     ln2, m2, r2 = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
-    hpre, hact = _linear(ln2, blk.mlp[0].weight, blk.mlp[0].bias, cx, act=2, out2=True)
+    # (GELU stays its own pass: fc1 writing both tensors is bound by the same two writes, measured equal or slower)
+    hpre = _linear(ln2, blk.mlp[0].weight, blk.mlp[0].bias, cx)
+    hact = ops.gelu_fwd(hpre)
     x2 = _linear(hact, blk.mlp[3].weight, blk.mlp[3].bias, cx, resid=x1, keep=keep2)
     if save is not None:
         save.append(("block", blk, pre, (x, m1, r1, ln1p, qkv, att, x1, m2, r2, ln2, hpre, hact, keep1, keep2,
@@ -315,8 +318,14 @@ def _block_bwd(blk, pre, ctx, dx2, cx, grads):
     padded = (He, We) != (H, W)
     # MLP branch
     db = ops.scale_sample(dx2, keep2) if keep2 is not None else dx2
-    dhp = _linear_bwd(hact, db, blk.mlp[3].weight, cx, grads, pre + "mlp.3.weight", pre + "mlp.3.bias",
-                      gelu_grad_of=hpre)
+    # d hidden = (d out @ W2) * GELU'(pre-activation): inside the GEMM's epilogue where the hidden tensor is
+    # large (it saves one write and one read of it); on the small late stages the separate pass is as fast
+    if hpre.numel() >= _FUSE_GELU_BWD_ELEMS:
+        dhp = _linear_bwd(hact, db, blk.mlp[3].weight, cx, grads, pre + "mlp.3.weight", pre + "mlp.3.bias",
+                          gelu_grad_of=hpre)
+    else:
+        dh = _linear_bwd(hact, db, blk.mlp[3].weight, cx, grads, pre + "mlp.3.weight", pre + "mlp.3.bias")
+        dhp = ops.gelu_bwd(dh, hpre)
     dln2 = _linear_bwd(ln2, dhp, blk.mlp[0].weight, cx, grads, pre + "mlp.0.weight", pre + "mlp.0.bias")
     dx1, grads[pre + "norm2.weight"], grads[pre + "norm2.bias"] = ops.layernorm_bwd(
         dln2, x1, blk.norm2.weight, m2, r2, add=dx2)
