@@ -96,7 +96,7 @@ class GradReducer:
         view = b.views[name]
         view.copy_(grad.reshape(view.shape))
         self._arrived(b)
-        return view
+        return view.detach()        # a fresh alias of the bucket memory, for autograd to keep as .grad
 
     def _make_hook(self, name):
         def hook(p):
