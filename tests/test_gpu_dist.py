@@ -44,6 +44,28 @@ def _step(model, name, rank):
 
 
 def _worker(rank, world, port, q):
+    try:
+        _worker_body(rank, world, port, q)
+    except BaseException:           # the parent must hear about it instead of waiting for the queue
+        import traceback
+        q.put(("error", rank, traceback.format_exc()))
+        raise
+
+
+def _digest(t):
+    """Small stand-in for a tensor that still pins every element: head, float64 sum, norm and a byte hash."""
+    import hashlib
+    a = t.detach().cpu().numpy()
+    return (a.reshape(-1)[:32].copy(), float(a.astype(np.float64).sum()), float(np.linalg.norm(a.astype(np.float64))),
+            hashlib.sha1(a.tobytes()).hexdigest())
+
+
+def _worker_body(rank, world, port, q):
+    import faulthandler
+    logdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    log = open(os.path.join(logdir, f"dist_rank{rank}.txt"), "w") if os.path.isdir(logdir) else None
+    if log is not None:
+        faulthandler.dump_traceback_later(100, exit=True, file=log)      # a stuck rank leaves its stack behind
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
     torch.cuda.set_device(0)
@@ -52,7 +74,14 @@ def _worker(rank, world, port, q):
     from unet_amd.optim import FusedAdamW
     out = {}
     for name, model in _models().items():
-        red = GradReducer(model, bucket_bytes=256 << 10)
+        # (gloo's CUDA-tensor collectives stall when issued from the autograd thread with both ranks on one
+        # card; the sum is staged through the host here, synchronously, still from inside the backward pass.
+        # On RCCL the default asynchronous all-reduce is used.)
+        def host_sum(flat):
+            cpu = flat.cpu()
+            dist.all_reduce(cpu)
+            flat.copy_(cpu)
+        red = GradReducer(model, bucket_bytes=(256 << 10) if name == "unet" else (8 << 20), collective=host_sum)
         assert model.grad_sink is not None and len(red.buckets) > 1
         opt = FusedAdamW(model.parameters(), lr=1e-3, weight_decay=0.01, max_grad_norm=1.0)
         for p in model.parameters():
@@ -61,10 +90,10 @@ def _worker(rank, world, port, q):
         launched = sum(b.work is not None for b in red.buckets)      # started inside the backward pass
         red.finish()
         torch.cuda.synchronize()
-        grads = {n: p.grad.detach().cpu().numpy().copy() for n, p in model.named_parameters()}
+        grads = {n: _digest(p.grad) for n, p in model.named_parameters()}
         opt.step()
         torch.cuda.synchronize()
-        params = {n: p.detach().cpu().numpy().copy() for n, p in model.named_parameters()}
+        params = {n: _digest(p)[3] for n, p in model.named_parameters()}
         out[name] = (grads, params, launched, len(red.buckets))
         red.detach()
         assert model.grad_sink is None
@@ -84,7 +113,20 @@ def test_two_rank_step_equals_mean_of_per_shard_gradients():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    gathered = q.get(timeout=400)
+    import queue
+    gathered = None
+    for _ in range(60):                        # fail as soon as a rank dies, not after a long silent wait
+        try:
+            gathered = q.get(timeout=2)
+            break
+        except queue.Empty:
+            if any(p.exitcode not in (None, 0) for p in procs):
+                break
+    if gathered is None or (isinstance(gathered, tuple) and gathered[0] == "error"):
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+        pytest.fail(f"a rank failed or timed out: {gathered}")
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -95,13 +137,18 @@ def test_two_rank_step_equals_mean_of_per_shard_gradients():
                 p.grad = None
             _step(model, name, r)
             torch.cuda.synchronize()
-            per_shard.append({n: p.grad.detach().cpu().numpy().copy() for n, p in model.named_parameters()})
+            per_shard.append({n: p.grad.detach().cpu().double() for n, p in model.named_parameters()})
         for r in range(world):
             grads, params, launched, nbuckets = gathered[r][name]
             assert launched >= nbuckets - 1, (name, launched, nbuckets)
             for n in per_shard[0]:
-                want = (per_shard[0][n] + per_shard[1][n]) / world
+                want = ((per_shard[0][n] + per_shard[1][n]) / world).numpy()
+                head, total, norm, _ = grads[n]
                 scale = max(float(np.abs(want).max()), 1e-12)
-                assert float(np.abs(grads[n] - want).max()) <= 1e-5 * scale + 1e-9, (name, r, n)
+                assert float(np.abs(head - want.reshape(-1)[:32]).max()) <= 1e-5 * scale + 1e-9, (name, r, n)
+                assert abs(norm - float(np.linalg.norm(want))) <= 1e-5 * float(np.linalg.norm(want)) + 1e-9, (name, r, n)
+                assert abs(total - float(want.sum())) <= 1e-4 * float(np.abs(want).sum()) + 1e-9, (name, r, n)
         for n in gathered[0][name][1]:
-            assert np.array_equal(gathered[0][name][1][n], gathered[1][name][1][n]), (name, n)   # replicas stay in step
+            assert gathered[0][name][1][n] == gathered[1][name][1][n], (name, n)   # replicas stay in step, bit for bit
+        for n in gathered[0][name][0]:
+            assert gathered[0][name][0][n][3] == gathered[1][name][0][n][3], (name, n)   # same reduced gradient on both

@@ -179,6 +179,80 @@ def test_training_step_oracle_matches_golden(golden):
     assert rel(heads, g["param_heads"]) < 1e-6
 
 
+@pytest.mark.parametrize("name,B,H,Wd", [("s256", 1, 256, 256), ("s24", 2, 24, 24)])
+def test_swin_oracle_matches_golden_full_size_and_resized_skip(golden, name, B, H, Wd):
+    """swin2.npz: the no-padding 256-px geometry of BASELINE config 3, and a 24-px input whose decoder resizes
+    the projected skips (swin_unet_model.py:526-529); float64 as in the generator."""
+    g = golden("swin2")
+    cfg = swin_oracle.DEFAULT_CONFIG
+    sd = W.fill_state_dict(swin_oracle.swin_template(cfg), seed=42)
+    x, y, _ = W.synthetic_batch(B, 4, H, Wd, seed=42)
+    if name == "s24":
+        o, _ = swin_oracle.swin_unet_forward(sd, x, cfg, False)
+        assert tuple(o.shape) == tuple(g["s24.out_shape"]) == (2, 1, 16, 16)
+        assert rel(sub(o, 16384), g["s24.eval_out"]) < 1e-5
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    params = {k: v.clone().requires_grad_(True) for k, v in sd64.items()
+              if v.is_floating_point() and "running_" not in k}
+    full = dict(sd64)
+    full.update(params)
+    out, stats = swin_oracle.swin_unet_forward(full, x.double(), cfg, True, None)
+    tgt = torch.nn.functional.interpolate(y.double(), size=out.shape[-2:], mode="bilinear", align_corners=False)
+    loss = ((out - tgt) ** 2).mean()
+    loss.backward()
+    assert abs(loss.item() - g[f"{name}.loss"]) < 1e-9
+    assert rel(sub(out, 16384), g[f"{name}.train_out"]) < 1e-10
+    names = [str(s) for s in g[f"{name}.param_names"]]
+    norms = np.array([params[k].grad.norm().item() for k in names])
+    keep = np.array([k != "final_conv.0.bias" for k in names])
+    assert rel(norms[keep], g[f"{name}.grad_norms"][keep]) < 1e-8
+
+
+def test_swin_training_step_oracle_matches_golden(golden):
+    """The Swin trainer's step (swin_unet_model.py:809-823) restated: resize to the label, 'tid_gradient' loss,
+    clip, AdamW(1e-4, 0.05), against the step frozen from the reference's own modules and torch.optim.AdamW."""
+    from oracle import step_oracle
+    g = golden("step_swin")
+    cfg = dict(swin_oracle.DEFAULT_CONFIG)
+    sd = W.fill_state_dict(swin_oracle.swin_template(cfg), seed=42)
+    x, y, w = W.synthetic_batch(2, 4, 64, 64, seed=42)
+    lcfg = loss_oracle.preset("weighted_mse_grad", grad_w=0.3, spec_w=0.0)
+    parts, norm, new, grads = step_oracle.swin_training_step(sd, x, y, w, cfg, lcfg)
+    got = np.array([parts[k] for k in ("pixel", "gradient", "spectral", "total")])
+    assert rel(got, g["parts"]) < 1e-5
+    assert abs(norm - float(g["grad_norm"])) < 1e-3 * float(g["grad_norm"])
+    names = [str(s) for s in g["param_names"]]
+    keep = np.array([k != "final_conv.0.bias" for k in names])
+    gn = np.array([grads[k].double().norm().item() for k in names])
+    assert rel(gn[keep], g["grad_norms"][keep]) < 5e-3
+    delta = np.array([(new[k] - sd[k]).double().norm().item() for k in names])
+    assert rel(delta[keep], g["param_delta_norms"][keep]) < 5e-3
+    heads = np.concatenate([sub(new[k], 8) for k in names])
+    assert rel(heads, g["param_heads"]) < 1e-4      # includes final_conv.0.bias: zero gradient, its Adam step is sign(noise)
+
+
+def test_bf16_fixture_is_the_reference_autocast_run(golden):
+    """bf16.npz holds the distance of the reference's bf16-autocast run from its fp32 run; the oracle's CPU model
+    of bf16 storage (every stored tensor class rounded) must land in the same place, which is what lets the
+    GPU tests bound the bf16 kernels by these numbers."""
+    from oracle import unet_oracle
+    g = golden("bf16")
+    for name, (cin, f, B, H, Wd) in {"small": (4, 8, 2, 32, 32), "odd": (4, 16, 1, 50, 36)}.items():
+        sd = W.fill_state_dict(W.unet_template(cin, 1, f), seed=42)
+        x, y, _ = W.synthetic_batch(B, cin, H, Wd, seed=42)
+        lf = lambda o: ((o - y) ** 2).mean()
+        o32, _, g32, _ = unet_oracle.unet_fwd_bwd(sd, x, lf)
+        o16, _, g16, _ = unet_oracle.unet_fwd_bwd(sd, x, lf, None, unet_oracle.BF16_ALL)
+        names = [k for k in g32 if k != "__input__"]
+        a = torch.cat([g16[k].double().reshape(-1) for k in names])
+        b = torch.cat([g32[k].double().reshape(-1) for k in names])
+        out_rel, grad_rel = rel(o16, o32), rel(a, b)
+        ref_out, ref_grad = float(g[f"unet.{name}.out_rel"]), float(g[f"unet.{name}.grad_rel"])
+        assert 0.5 * ref_out < out_rel < 1.5 * ref_out, (name, out_rel, ref_out)
+        assert 0.5 * ref_grad < grad_rel < 1.5 * ref_grad, (name, grad_rel, ref_grad)
+    assert 0.015 < float(g["swin.s256.eval_rel"]) < 0.025 and float(g["swin.s64.grad_cos"]) > 0.97
+
+
 PATCH_CASES = [("p16", 96, 112, 16, 8, 0.25, 21), ("p32", 160, 128, 32, 16, 0.25, 22), ("p8", 40, 33, 8, 3, 0.5, 23)]
 
 

@@ -35,10 +35,23 @@ class _Bucket:
         self.work = None
 
 
+class _Done:
+    def wait(self):
+        return True
+
+
+_DONE = _Done()
+
+
 class GradReducer:
-    def __init__(self, module: torch.nn.Module, bucket_bytes: int = 32 << 20, process_group=None):
+    def __init__(self, module: torch.nn.Module, bucket_bytes: int = 32 << 20, process_group=None, collective=None):
+        """``collective(flat)``: starts the sum over the ranks of one flat bucket in place and returns an
+        object with ``wait()`` (or None when it has already finished).  Default: an asynchronous
+        ``dist.all_reduce`` (RCCL: enqueued on the communicator's stream behind the kernels queued so far)."""
         self.module = module
         self.group = process_group
+        self._collective = collective if collective is not None else (
+            lambda flat: dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
         self.params = dict(named)
@@ -85,7 +98,7 @@ class GradReducer:
         b.pending -= 1
         if b.pending == 0:
             # the collective is ordered after everything queued so far on the current stream
-            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            b.work = self._collective(b.flat) or _DONE
 
     def _sink(self, name: str, grad: torch.Tensor) -> torch.Tensor:
         """Called from inside a model's backward with a freshly produced gradient; returns the bucket
@@ -124,7 +137,7 @@ class GradReducer:
                             self.params[n].grad.data_ptr() != b.views[n].data_ptr():
                         b.views[n].copy_(self.params[n].grad)
                 b.pending = 0
-                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                b.work = self._collective(b.flat) or _DONE
         inv = 1.0 / self.world
         for b in self.buckets:
             b.work.wait()
