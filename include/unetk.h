@@ -105,6 +105,16 @@ int unetk_linear_fwd(const void* x, int ldx, const void* wpacked, void* out, int
                      int ldr, const float* resid_keep, int64_t tok_per_sample, const void* gelu_grad_of, int ldaux,
                      unetk_stream_t stream);
 
+/* Weight and bias gradient of a token linear (autograd of the products above):
+ *   dw[n][k] (+)= sum_t dy[t][n] * x[t][k],   dbias[n] (+)= sum_t dy[t][n]  (dbias nullable).
+ * bfloat16 operands, fp32 results; workspace (fp32 partial tiles of the token ranges, summed in a fixed
+ * order) sized by unetk_token_wgrad_workspace_bytes. */
+int unetk_token_wgrad_supported(int64_t M, int K, int N, int dtype);
+int64_t unetk_token_wgrad_workspace_bytes(int64_t M, int K, int N);
+int unetk_token_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, float* dbias, int64_t M, int K,
+                      int N, int dtype, void* workspace, int64_t workspace_bytes, int accumulate,
+                      unetk_stream_t stream);
+
 /* ---- layout ------------------------------------------------------------------------ */
 int unetk_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int ld, int dtype,
                        unetk_stream_t stream);
@@ -136,6 +146,13 @@ int unetk_bn_act_bwd(const void* g, const void* y, void* dy, int B, int H, int W
                      const float* scale, const float* shift, const float* mean, const float* invstd,
                      const float* keep, int relu, float* dgamma, float* dbeta, int accumulate,
                      float* partials, float* sums, int dtype, unetk_stream_t stream);
+/* Same with a rank-one gradient that is never stored: g[b,y,x,c] = gpix[b,y,x] * gchan[c] (rounded to the
+ * compute type as the stored tensor would be).  The gradient of the last activation of the UNet is of this
+ * form: dout (B,1,H,W) times the weight of the final 1x1 conv (training.py:482, 520). */
+int unetk_bn_act_bwd_rank1(const float* gpix, const float* gchan, const void* y, void* dy, int B, int H, int W, int C,
+                           const float* scale, const float* shift, const float* mean, const float* invstd,
+                           const float* keep, int relu, float* dgamma, float* dbeta, int accumulate,
+                           float* partials, float* sums, int dtype, unetk_stream_t stream);
 /* da = dskip + route(dpooled to the first maximum of each 2x2 quad): the maximum is taken from
  * argmax when given (a may then be null), else recomputed from a. */
 int unetk_pool_bwd(const void* a, const unsigned char* argmax, const void* dpooled, const void* dskip,

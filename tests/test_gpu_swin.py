@@ -168,6 +168,33 @@ def test_token_linear_gemm(shape):
         assert rel(ops.linear_fwd(dy.to("cuda", dt), pwt), dy.double() @ w.double()) < 1e-2
 
 
+@pytest.mark.parametrize("shape", [(2, 5, 7, 96, 288), (1, 16, 16, 384, 96), (3, 8, 8, 192, 768), (1, 8, 8, 768, 2304),
+                                   (2, 9, 4, 64, 96), (4, 32, 32, 96, 96), (2, 16, 8, 512, 1024), (1, 4, 4, 96, 32),
+                                   (8, 64, 64, 96, 384)])
+def test_token_weight_gradient_gemm(shape):
+    """dw = dy^T x and db = column sums of dy from the bf16 token weight-gradient kernel against float64, on
+    exactly representable inputs; token counts that are not stage multiples, channel counts that are not tile
+    multiples, strided (channel-slice) operands."""
+    from unet_amd import ops
+    B, H, Wd, K, N = shape
+    dt = torch.bfloat16
+    x = rnd((B, H, Wd, K), 31, dt, 0.7)
+    dy = rnd((B, H, Wd, N), 32, dt, 0.5)
+    xd, dyd = x.to("cuda", dt), dy.to("cuda", dt)
+    assert ops.token_wgrad_supported(xd, dyd, K, N)
+    dw, db = ops.token_wgrad(xd, dyd, K, N)
+    want = dy.double().reshape(-1, N).t() @ x.double().reshape(-1, K)
+    assert rel(dw, want) < 1e-5, rel(dw, want)
+    assert rel(db, dy.double().reshape(-1, N).sum(0)) < 1e-5
+    dw2, none = ops.token_wgrad(xd, dyd, K, N, want_bias=False)
+    assert none is None and torch.equal(dw2, dw)
+    # operands that are channel slices of wider tensors
+    xw = torch.zeros((B, H, Wd, K + 16), dtype=dt, device="cuda")
+    xw[..., 8:8 + K] = xd
+    dw3, _ = ops.token_wgrad(xw[..., 8:8 + K], dyd, K, N)
+    assert torch.equal(dw3, dw)
+
+
 def build(dt):
     from unet_amd.swin import SwinUNet
     cfg = dict(swin_oracle.DEFAULT_CONFIG)

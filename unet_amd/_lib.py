@@ -45,6 +45,9 @@ _SIGNATURES = {
     "unetk_linear_wgrad": (I, [P, I, P, I, P, P, L, I, I, I, P, L, I, P]),
     "unetk_linear_supported": (I, [L, I, I, I, I]),
     "unetk_linear_fwd": (I, [P, I, P, P, I, P, I, L, I, I, I, I, P, I, P, I, P, L, P, I, P]),
+    "unetk_token_wgrad_supported": (I, [L, I, I, I]),
+    "unetk_token_wgrad_workspace_bytes": (L, [L, I, I]),
+    "unetk_token_wgrad": (I, [P, I, P, I, P, P, L, I, I, I, P, L, I, P]),
     "unetk_optim_chunk_elems": (I, []),
     "unetk_grad_norm": (I, [P, P, P, I, F, P, P, P]),
     "unetk_scale_list": (I, [P, P, P, I, P, P]),
@@ -63,6 +66,7 @@ _SIGNATURES = {
     "unetk_bn_act_fwd": (I, [P, I, P, I, P, P, I, I, I, I, P, P, P, I, I, P]),
     "unetk_reduce_num_partials": (I, [L]),
     "unetk_bn_act_bwd": (I, [P, P, P, I, I, I, I, P, P, P, P, P, I, P, P, I, P, P, I, P]),
+    "unetk_bn_act_bwd_rank1": (I, [P, P, P, P, I, I, I, I, P, P, P, P, P, I, P, P, I, P, P, I, P]),
     "unetk_pool_bwd": (I, [P, P, P, P, I, P, I, I, I, I, I, P]),
     "unetk_upsample_concat_fwd": (I, [P, I, I, I, P, I, I, P, I, I, I, I, P]),
     "unetk_upsample_bwd": (I, [P, I, I, I, P, I, I, I, I, I, P]),

@@ -27,6 +27,8 @@
 //
 // Weights arrive in the packed layout of the convolution kernels for kernel size 1,
 // [N/BN][K/32][BN][32]: a stage's weight slab is one contiguous run.
+#include <stdlib.h>
+
 #include "common.h"
 #include "mma.h"
 
@@ -60,6 +62,8 @@ __device__ __forceinline__ void wait_vm_barrier_g(int n) {
 #define UNETK_WVB(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_barrier" ::: "memory"); break;
   switch (n) {
     UNETK_WVB(1) UNETK_WVB(2) UNETK_WVB(3) UNETK_WVB(4) UNETK_WVB(5) UNETK_WVB(6) UNETK_WVB(7) UNETK_WVB(8)
+    UNETK_WVB(9) UNETK_WVB(10) UNETK_WVB(11) UNETK_WVB(12) UNETK_WVB(13) UNETK_WVB(14) UNETK_WVB(15) UNETK_WVB(16)
+    UNETK_WVB(18) UNETK_WVB(20) UNETK_WVB(21) UNETK_WVB(24)
     default: asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); break;
   }
 #undef UNETK_WVB
@@ -236,6 +240,260 @@ __global__ __launch_bounds__(256) void lin_gemm_kernel(GemmArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of a token linear:  dw[n][k] = sum_t dy[t][n] * x[t][k]   (and db[n] = sum_t dy[t][n])
+//
+// The reduction runs over tokens, the slow axis of both operands, so the MFMA fragments (eight
+// consecutive tokens of one channel per lane) are read from token-major LDS images with the
+// transposing ds_read_b64_tr_b16.  A workgroup of WM x WN waves owns a 64*WM x 64*WN tile of dw (each
+// wave a 64 x 64 block: 4 x 4 MFMA tiles) and a contiguous range of tokens, which it streams in
+// 32-token stages through a ring of three LDS stages filled by LDS-DMA (one counted wait + barrier
+// per stage, 16 MFMAs per wave between barriers).  No wave splits the reduction, so nothing is summed
+// through LDS at the end.  Partial tiles of the token ranges go to fp32 slabs [range][N_pad][K_pad];
+// a second kernel adds the slabs in a fixed order (bitwise reproducible, no atomics).
+// LDS rows are 256 or 512 bytes (a whole number of bank rows), so a transposing read, which per
+// 32-lane half touches tokens {o..o+3, o+8..o+11} at one 32-byte channel unit, would hit one unit
+// eight times: the 32-byte unit index inside each 256 bytes is XORed with (token&3) | (token bit 3)<<2,
+// on the DMA source address and on the read address alike.
+struct WgArgs {
+  const bf16* x;
+  const bf16* dy;
+  float* slab;          // [nsplit][N_pad][K_pad]
+  float* bias_slab;     // [nsplit][N_pad] or null
+  int ldx, lddy;
+  int M, N, K, N_pad, K_pad;
+  int nsplit, chunk;    // token ranges: [s*chunk, (s+1)*chunk)
+  int gn, gk;           // output tiles along N and K
+};
+
+__device__ __forceinline__ int tok_key(int t) { return (t & 3) | (((t >> 3) & 1) << 2); }
+
+template <int WM, int WN, int NSTAGE>
+__global__ __launch_bounds__(64 * WM * WN) void lin_wgrad_kernel(WgArgs a) {
+  constexpr int NW = WM * WN, NTHR = 64 * NW;
+  constexpr int BNo = 64 * WM, BKo = 64 * WN;
+  constexpr int RBD = 2 * BNo, RBX = 2 * BKo;            // LDS row bytes of the dy / x images
+  constexpr int TT = 32;                                 // tokens per stage = one MFMA k-step
+  constexpr int DPIECES = TT * RBD / 1024, XPIECES = TT * RBX / 1024;
+  constexpr int DBYTES = TT * RBD, STAGE = TT * (RBD + RBX);
+  constexpr int AHEAD = NSTAGE - 1;                      // stages in flight behind the one being multiplied
+  __shared__ __attribute__((aligned(1024))) char lds[NSTAGE * STAGE];
+  static_assert(RBD % 256 == 0 && RBX % 256 == 0, "rows are whole bank rows");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  // workgroups that stream the same token range (different tiles of dw) get ids that differ by
+  // multiples of 8: one XCD, dispatched back to back, so the range is fetched from HBM once
+  const int gxy = a.gn * a.gk;
+  const int lin = blockIdx.x;
+  const bool xcd_map = (a.nsplit & 7) == 0;
+  const int cxy = xcd_map ? (lin >> 3) % gxy : lin % gxy;
+  const int sp = xcd_map ? ((lin >> 3) / gxy) * 8 + (lin & 7) : lin / gxy;
+  const int n0 = (cxy / a.gk) * BNo, k0 = (cxy % a.gk) * BKo;
+  const int t_begin = sp * a.chunk;
+  const int t_end = (t_begin + a.chunk < a.M) ? t_begin + a.chunk : a.M;
+  const int nstage = t_begin < t_end ? (t_end - t_begin + TT - 1) / TT : 0;
+
+  // ---- DMA sources: piece i is 1 KiB of the image; lane -> (token, 16-byte slot) of the image, whose
+  // source slot is the swizzled one.  Channels past N / K and tokens past the range read zeros.
+  constexpr int DPW = (DPIECES + NW - 1) / NW, XPW = (XPIECES + NW - 1) / NW;
+  const bf16* zero = reinterpret_cast<const bf16*>(gemm_zero_page);
+  int d_tok[DPW], d_off[DPW], x_tok[XPW], x_off[XPW];      // token in the stage (or 1 << 20: nothing to load)
+#pragma unroll
+  for (int k = 0; k < DPW; ++k) {
+    const int i = wave + NW * k;
+    const int o = i * 1024 + lane * 16;
+    const int t = o / RBD, sl = (o % RBD) / 16;
+    const int ss = (sl & ~15) | ((sl & 15) ^ (tok_key(t) << 1));
+    const int c = n0 + ss * 8;
+    d_tok[k] = (i < DPIECES && c < a.N) ? t : (1 << 20);
+    d_off[k] = t * a.lddy + c;
+  }
+#pragma unroll
+  for (int k = 0; k < XPW; ++k) {
+    const int i = wave + NW * k;
+    const int o = i * 1024 + lane * 16;
+    const int t = o / RBX, sl = (o % RBX) / 16;
+    const int ss = (sl & ~15) | ((sl & 15) ^ (tok_key(t) << 1));
+    const int c = k0 + ss * 8;
+    x_tok[k] = (i < XPIECES && c < a.K) ? t : (1 << 20);
+    x_off[k] = t * a.ldx + c;
+  }
+  auto issue = [&](int st) {
+    char* dst = lds + (st % NSTAGE) * STAGE;
+    const int t0 = t_begin + st * TT;
+    const bf16* dbase = a.dy + (long)t0 * a.lddy;
+    const bf16* xbase = a.x + (long)t0 * a.ldx;
+#pragma unroll
+    for (int k = 0; k < DPW; ++k) {
+      const int i = wave + NW * k;
+      if (i < DPIECES) glds16g(t0 + d_tok[k] < t_end ? dbase + d_off[k] : zero, dst + i * 1024);
+    }
+#pragma unroll
+    for (int k = 0; k < XPW; ++k) {
+      const int i = wave + NW * k;
+      if (i < XPIECES) glds16g(t0 + x_tok[k] < t_end ? xbase + x_off[k] : zero, dst + DBYTES + i * 1024);
+    }
+  };
+  const int my_pieces = (DPIECES - wave + NW - 1) / NW + (XPIECES - wave + NW - 1) / NW;
+
+  // ---- transposing-read addresses: group g = lane/16 reads tokens 8g+4h+q (h = 0, 1), lane (q, p) of the
+  // group supplies channels 4p..4p+3 of the 16-channel tile
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, p4 = li & 3;
+  const int key = q | ((g & 1) << 2);
+  int a_addr[4], b_addr[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int sd = wm * 8 + 2 * m + (p4 >> 1);
+    a_addr[m] = (8 * g + q) * RBD + (((sd & ~15) | ((sd & 15) ^ (key << 1))) * 16) + (p4 & 1) * 8;
+    const int sx = wn * 8 + 2 * m + (p4 >> 1);
+    b_addr[m] = DBYTES + (8 * g + q) * RBX + (((sx & ~15) | ((sx & 15) ^ (key << 1))) * 16) + (p4 & 1) * 8;
+  }
+
+  f32x4 acc[4][4], accb[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    accb[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool want_bias = a.bias_slab != nullptr && wn == 0 && k0 == 0;
+
+#pragma unroll
+  for (int k = 0; k < AHEAD; ++k)
+    if (k < nstage) issue(k);
+#pragma unroll 1
+  for (int st = 0; st < nstage; ++st) {
+    // this stage's pieces have landed once at most the pieces of the younger stages in flight remain
+    const int younger = nstage - 1 - st < AHEAD - 1 ? nstage - 1 - st : AHEAD - 1;
+    wait_vm_barrier_g(younger * my_pieces);
+    if (st + AHEAD < nstage) issue(st + AHEAD);
+    const char* base = lds + (st % NSTAGE) * STAGE;
+    bf16x8 af[4], bfr[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, base + a_addr[m]));
+      const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, base + a_addr[m] + 4 * RBD));
+      typedef __attribute__((ext_vector_type(8))) short short8v;
+      af[m] = __builtin_bit_cast(bf16x8, short8v{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, base + b_addr[n]));
+      const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, base + b_addr[n] + 4 * RBX));
+      typedef __attribute__((ext_vector_type(8))) short short8v;
+      bfr[n] = __builtin_bit_cast(bf16x8, short8v{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
+    if (want_bias) {      // (wave-uniform) dy^T times a matrix of ones: every column = the sum over the stage's tokens
+      const u32x4 ones = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        accb[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], __builtin_bit_cast(bf16x8, ones), accb[m], 0, 0, 0);
+    }
+  }
+
+  // slab[sp][n][k]; C layout: column (k) = lane&15, row (n) = 4*(lane>>4) + r
+  float* slab = a.slab + (long)sp * a.N_pad * a.K_pad;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = n0 + wm * 64 + m * 16 + 4 * g + r;
+        const int col = k0 + wn * 64 + n * 16 + li;
+        slab[(long)row * a.K_pad + col] = acc[m][n][r];
+      }
+  if (want_bias && li == 0) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a.bias_slab[(long)sp * a.N_pad + n0 + wm * 64 + m * 16 + 4 * g + r] = accb[m][r];
+  }
+}
+
+// dw[n][k] (+)= sum_s slab[s][n][k], db[n] (+)= sum_s bias_slab[s][n].  A workgroup owns 64 quads of dw and
+// four slab lanes: lane j sums the slabs j, j+4, ... in order, then the four lane sums are added in lane
+// order: the same bits every run, four times the loads in flight.
+__global__ __launch_bounds__(256) void lin_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                               const float* __restrict__ bias_slab,
+                                                               float* __restrict__ db, int nsplit, int N, int K,
+                                                               int N_pad, int K_pad, int accumulate, int nmain_blocks) {
+  __shared__ f32x4 part[4][64];
+  if ((int)blockIdx.x >= nmain_blocks) {
+    const int n = (blockIdx.x - nmain_blocks) * 256 + threadIdx.x;
+    if (db != nullptr && n < N) {
+      float s = 0.f;
+      for (int i = 0; i < nsplit; ++i) s += bias_slab[(long)i * N_pad + n];
+      db[n] = accumulate ? db[n] + s : s;
+    }
+    return;
+  }
+  const int k4 = K / 4;
+  const long nquads = (long)N * k4;
+  const int e = threadIdx.x & 63, j = threadIdx.x >> 6;
+  const long idx = (long)blockIdx.x * 64 + e;
+  f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+  int n = 0, kq = 0;
+  if (idx < nquads) {
+    n = idx / k4;
+    kq = idx - (long)n * k4;
+    const float* p = slab + (long)n * K_pad + kq * 4;
+    const long stride = (long)N_pad * K_pad;
+    int i = j;
+    for (; i + 12 < nsplit; i += 16) {
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + i * stride);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (i + 4) * stride);
+      const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (i + 8) * stride);
+      const f32x4 v3 = *reinterpret_cast<const f32x4*>(p + (i + 12) * stride);
+      s = (((s + v0) + v1) + v2) + v3;
+    }
+    for (; i < nsplit; i += 4) s += *reinterpret_cast<const f32x4*>(p + i * stride);
+  }
+  part[j][e] = s;
+  __syncthreads();
+  if (j == 0 && idx < nquads) {
+    const f32x4 t = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
+    f32x4* d = reinterpret_cast<f32x4*>(dw + (long)n * K + kq * 4);
+    *d = accumulate ? (*d + t) : t;
+  }
+}
+
+struct WgPlan {
+  int wm, N_pad, K_pad, gn, gk, nsplit, chunk;
+};
+
+inline WgPlan plan_lin_wgrad(long M, int K, int N) {
+  WgPlan p;
+  // 256 x 128 tiles (8 waves, one workgroup per CU) where dw is large enough to fill the chip with them
+  // and deep enough in tokens; else 128 x 128 (4 waves, three per CU)
+  p.wm = 2;
+  if (const char* e = getenv("UNETK_WG_WM")) p.wm = atoi(e) == 4 ? 4 : 2;
+  const int bn = 64 * p.wm, bk = 128;
+  p.N_pad = cdiv(N, bn) * bn;
+  p.K_pad = cdiv(K, bk) * bk;
+  p.gn = p.N_pad / bn;
+  p.gk = p.K_pad / bk;
+  const long tiles = (long)p.gn * p.gk;
+  const long slots = p.wm == 4 ? 256L : 256L * 3;
+  long s = (slots + tiles - 1) / tiles;
+  long smax = (M + 255) / 256;                  // at least 8 stages of 32 tokens per workgroup
+  if (smax > 256) smax = 256;                   // ... and at most 256 partial tiles per tile of dw
+  if (s > smax) s = smax;
+  if (s < 1) s = 1;
+  if (s >= 8) s = (s + 7) / 8 * 8;              // multiples of 8 enable the XCD-aware order
+  p.nsplit = (int)s;
+  p.chunk = (int)(((M + s - 1) / s + 31) / 32 * 32);
+  return p;
+}
+
 template <int TM, int TN> int launch_gemm(GemmArgs a, hipStream_t stream) {
   constexpr int BM = 64 * TM;
   a.mtiles = cdiv(a.M, BM);
@@ -291,6 +549,49 @@ int unetk_linear_fwd(const void* x, int ldx, const void* wpacked, void* out, int
     case 64: return launch_gemm<2, 4>(a, stream);
     default: return launch_gemm<2, 2>(a, stream);
   }
+}
+
+int unetk_token_wgrad_supported(int64_t M, int K, int N, int dtype) {
+  return dtype == UNETK_BF16 && M > 0 && M < (1LL << 31) - 64 && K > 0 && N > 0 && K % 8 == 0 && N % 8 == 0;
+}
+
+int64_t unetk_token_wgrad_workspace_bytes(int64_t M, int K, int N) {
+  const WgPlan p = plan_lin_wgrad(M, K, N);
+  return (int64_t)p.nsplit * p.N_pad * (p.K_pad + 1) * 4;
+}
+
+int unetk_token_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, float* dbias, int64_t M, int K,
+                      int N, int dtype, void* workspace, int64_t workspace_bytes, int accumulate,
+                      hipStream_t stream) {
+  UNETK_CHECK_ARG(x && dy && dw && workspace, "token_wgrad: null pointer");
+  UNETK_CHECK_ARG(unetk_token_wgrad_supported(M, K, N, dtype),
+                  "token_wgrad: unsupported shape or type (M=%lld K=%d N=%d dtype %d): bfloat16, channel counts "
+                  "multiples of 8", (long long)M, K, N, dtype);
+  UNETK_CHECK_ARG(ldx >= K && lddy >= N && ldx % 8 == 0 && lddy % 8 == 0, "token_wgrad: bad strides");
+  UNETK_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)dw % 16) == 0,
+                  "token_wgrad: pointers must be 16-byte aligned");
+  UNETK_CHECK_ARG((int64_t)M * (ldx > lddy ? ldx : lddy) < (1LL << 31) * 32,
+                  "token_wgrad: tensor too large for the 32-bit stage offsets");
+  UNETK_CHECK_ARG(K % 4 == 0, "token_wgrad: K must be a multiple of 4");
+  const WgPlan p = plan_lin_wgrad(M, K, N);
+  const int64_t main_bytes = (int64_t)p.nsplit * p.N_pad * p.K_pad * 4;
+  const int64_t need = main_bytes + (int64_t)p.nsplit * p.N_pad * 4;
+  UNETK_CHECK_ARG(workspace_bytes >= need, "token_wgrad: workspace %lld < %lld bytes", (long long)workspace_bytes,
+                  (long long)need);
+  WgArgs a;
+  a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.slab = (float*)workspace;
+  a.bias_slab = dbias ? (float*)((char*)workspace + main_bytes) : nullptr;
+  a.ldx = ldx; a.lddy = lddy; a.M = (int)M; a.N = N; a.K = K; a.N_pad = p.N_pad; a.K_pad = p.K_pad;
+  a.nsplit = p.nsplit; a.chunk = p.chunk; a.gn = p.gn; a.gk = p.gk;
+  const unsigned grid = (unsigned)(p.gn * p.gk * p.nsplit);
+  if (p.wm == 4) hipLaunchKernelGGL((lin_wgrad_kernel<4, 2, 5>), dim3(grid), dim3(512), 0, stream, a);
+  else hipLaunchKernelGGL((lin_wgrad_kernel<2, 2, 3>), dim3(grid), dim3(256), 0, stream, a);
+  UNETK_CHECK_LAUNCH();
+  const int nmain = cdiv((long)N * (K / 4), 64);
+  hipLaunchKernelGGL(lin_wgrad_reduce_kernel, dim3((unsigned)(nmain + (dbias ? cdiv(N, 256) : 0))), dim3(256), 0, stream,
+                     a.slab, dw, a.bias_slab, dbias, p.nsplit, N, K, p.N_pad, p.K_pad, accumulate, nmain);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
 }
 
 }  // extern "C"

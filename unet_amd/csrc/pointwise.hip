@@ -275,6 +275,8 @@ struct RedArgs {
   const float* invstd;
   const float* keep;    // [B][C] or null
   float* partials;      // [nblk][2][C]
+  const float* g1_d;    // MODE 0, rank-one gradient: g[p][c] = round_T(g1_d[p] * g1_w[c]) instead of reading g
+  const float* g1_w;
   long npix, hw;
   int C, ldx, ldg, chunk, relu;
 };
@@ -329,6 +331,26 @@ __global__ __launch_bounds__(RED_THREADS) void channel_reduce_kernel(RedArgs a) 
           }
         };
         long p = seg + pl;
+        if (a.g1_d != nullptr) {
+          // the gradient of the last activation is an outer product (per-pixel scalar x per-channel
+          // weight of the final 1x1 conv): formed here, rounded as the stored tensor would be
+          float wv[E];
+#pragma unroll
+          for (int e = 0; e < E; ++e) wv[e] = a.g1_w[c0 + e];
+          auto gen = [&](long pp) {
+            const float d = a.g1_d[pp];
+            Vec16<T> gv;
+#pragma unroll
+            for (int e = 0; e < E; ++e) gv.v[e] = from_f32<T>(d * wv[e]);
+            return gv;
+          };
+          for (; p + lanes < seg_end; p += 2 * lanes) {
+            const Vec16<T> x0 = load16(x + p * a.ldx + c0), x1 = load16(x + (p + lanes) * a.ldx + c0);
+            one(x0, gen(p));
+            one(x1, gen(p + lanes));
+          }
+          if (p < seg_end) one(load16(x + p * a.ldx + c0), gen(p));
+        } else {
         for (; p + lanes < seg_end; p += 2 * lanes) {   // two pixels in flight
           const Vec16<T> x0 = load16(x + p * a.ldx + c0), g0 = load16(gp + p * a.ldg + c0);
           const Vec16<T> x1 = load16(x + (p + lanes) * a.ldx + c0), g1 = load16(gp + (p + lanes) * a.ldg + c0);
@@ -336,6 +358,7 @@ __global__ __launch_bounds__(RED_THREADS) void channel_reduce_kernel(RedArgs a) 
           one(x1, g1);
         }
         if (p < seg_end) one(load16(x + p * a.ldx + c0), load16(gp + p * a.ldg + c0));
+        }
         seg = seg_end;
       }
     } else {
@@ -474,7 +497,8 @@ template <int E> __device__ __forceinline__ void load_params(const float* p, flo
 template <typename T>
 __global__ __launch_bounds__(RED_THREADS) void bn_act_bwd_apply_kernel(
     const T* __restrict__ g, const T* __restrict__ y, T* __restrict__ dy, unsigned npix, unsigned hw, int C,
-    const float* __restrict__ coef, const float* __restrict__ keep, int relu, unsigned chunk) {
+    const float* __restrict__ coef, const float* __restrict__ keep, int relu, unsigned chunk,
+    const float* __restrict__ g1_d, const float* __restrict__ g1_w) {
   constexpr int E = Vec16<T>::N;
   const int CG = C / E;
   const int lanes = RED_THREADS / CG;
@@ -489,9 +513,19 @@ __global__ __launch_bounds__(RED_THREADS) void bn_act_bwd_apply_kernel(
   const unsigned pbeg = blockIdx.x * chunk;
   unsigned pend = pbeg + chunk;
   if (pend > npix) pend = npix;
+  float wv[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) wv[e] = g1_d != nullptr ? g1_w[c0 + e] : 0.f;
   for (unsigned p = pbeg + pl; p < pend; p += lanes) {
     const size_t off = (size_t)p * C + c0;
-    Vec16<T> gv = load16(g + off);
+    Vec16<T> gv;
+    if (g1_d != nullptr) {      // (uniform) rank-one gradient formed on the fly
+      const float d = g1_d[p];
+#pragma unroll
+      for (int e = 0; e < E; ++e) gv.v[e] = from_f32<T>(d * wv[e]);
+    } else {
+      gv = load16(g + off);
+    }
     Vec16<T> yv = load16(y + off);
     float kp[E];
     if (keep != nullptr) {
@@ -1036,11 +1070,11 @@ int unetk_bn_act_fwd(const void* y, int ldy, void* a, int lda, void* pooled, uns
 
 int unetk_reduce_num_partials(int64_t npix) { return reduce_blocks(npix); }
 
-int unetk_bn_act_bwd(const void* g, const void* y, void* dy, int B, int H, int W, int C,
-                     const float* scale, const float* shift, const float* mean, const float* invstd,
-                     const float* keep, int relu, float* dgamma, float* dbeta, int accumulate,
-                     float* partials, float* sums, int dtype, hipStream_t stream) {
-  UNETK_CHECK_ARG(g && y && dy && scale && shift && mean && invstd && partials && sums,
+static int bn_act_bwd_impl(const void* g, const float* g1_d, const float* g1_w, const void* y, void* dy, int B, int H,
+                           int W, int C, const float* scale, const float* shift, const float* mean,
+                           const float* invstd, const float* keep, int relu, float* dgamma, float* dbeta,
+                           int accumulate, float* partials, float* sums, int dtype, hipStream_t stream) {
+  UNETK_CHECK_ARG((g || (g1_d && g1_w)) && y && dy && scale && shift && mean && invstd && partials && sums,
                   "bn_act_bwd: null pointer");
   CHECK_DTYPE("bn_act_bwd", dtype);
   CHECK_VEC("bn_act_bwd", dtype, C);
@@ -1052,7 +1086,7 @@ int unetk_bn_act_bwd(const void* g, const void* y, void* dy, int B, int H, int W
   RedArgs r;
   r.x = y; r.g = g; r.scale = scale; r.shift = shift; r.mean = mean; r.invstd = invstd; r.keep = keep;
   r.partials = partials; r.npix = npix; r.hw = (long)H * W; r.C = C; r.ldx = C; r.ldg = C;
-  r.chunk = cdiv(npix, nblk); r.relu = relu;
+  r.chunk = cdiv(npix, nblk); r.relu = relu; r.g1_d = g1_d; r.g1_w = g1_w;
   DISPATCH_T(dtype, hipLaunchKernelGGL((channel_reduce_kernel<T, 0>), dim3(nblk), dim3(RED_THREADS), 0,
                                        stream, r));
   UNETK_CHECK_LAUNCH();
@@ -1070,10 +1104,29 @@ int unetk_bn_act_bwd(const void* g, const void* y, void* dy, int B, int H, int W
     const unsigned chunk = (unsigned)((npix + nb - 1) / nb);
     DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_bwd_apply_kernel<T>, dim3((unsigned)cdiv(npix, chunk)),
                                          dim3(RED_THREADS), 0, stream, (const T*)g, (const T*)y, (T*)dy,
-                                         (unsigned)npix, (unsigned)((long)H * W), C, coef, keep, relu, chunk));
+                                         (unsigned)npix, (unsigned)((long)H * W), C, coef, keep, relu, chunk,
+                                         g1_d, g1_w));
   }
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
+}
+
+int unetk_bn_act_bwd(const void* g, const void* y, void* dy, int B, int H, int W, int C,
+                     const float* scale, const float* shift, const float* mean, const float* invstd,
+                     const float* keep, int relu, float* dgamma, float* dbeta, int accumulate,
+                     float* partials, float* sums, int dtype, hipStream_t stream) {
+  UNETK_CHECK_ARG(g != nullptr, "bn_act_bwd: null gradient");
+  return bn_act_bwd_impl(g, nullptr, nullptr, y, dy, B, H, W, C, scale, shift, mean, invstd, keep, relu, dgamma, dbeta,
+                         accumulate, partials, sums, dtype, stream);
+}
+
+int unetk_bn_act_bwd_rank1(const float* gpix, const float* gchan, const void* y, void* dy, int B, int H, int W, int C,
+                           const float* scale, const float* shift, const float* mean, const float* invstd,
+                           const float* keep, int relu, float* dgamma, float* dbeta, int accumulate,
+                           float* partials, float* sums, int dtype, hipStream_t stream) {
+  UNETK_CHECK_ARG(gpix && gchan, "bn_act_bwd_rank1: null gradient factors");
+  return bn_act_bwd_impl(nullptr, gpix, gchan, y, dy, B, H, W, C, scale, shift, mean, invstd, keep, relu, dgamma,
+                         dbeta, accumulate, partials, sums, dtype, stream);
 }
 
 int unetk_pool_bwd(const void* a, const unsigned char* argmax, const void* dpooled, const void* dskip,
@@ -1189,6 +1242,7 @@ int unetk_head1x1_bwd(const void* x, int ldx, const float* w, const float* dout,
     for (int o = 0; o < Co; ++o) {
       RedArgs r;
       r.x = x; r.g = dout + (long)o * H * W; r.scale = r.shift = r.mean = r.invstd = r.keep = nullptr;
+      r.g1_d = r.g1_w = nullptr;
       r.partials = partials; r.npix = npix; r.hw = (long)H * W; r.C = C; r.ldx = ldx; r.ldg = 1;
       r.chunk = cdiv(npix, nblk); r.relu = 0;
       DISPATCH_T(dtype, hipLaunchKernelGGL((channel_reduce_kernel<T, 1>), dim3(nblk), dim3(RED_THREADS), 0,

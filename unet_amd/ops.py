@@ -236,12 +236,43 @@ def linear_fwd(x, pw: PackedConv, bias=None, act=0, resid=None, resid_keep=None,
     return (out, second) if out2 else out
 
 
-def linear_wgrad(x: torch.Tensor, dy: torch.Tensor, Ci: int, Co: int):
-    """(dw (Co,Ci), db (Co,)) fp32 of a linear layer over tokens: x (..., ldx) and dy (..., lddy) channels-last.
-    bfloat16 with unpadded channel counts: one pass over dy gives both; otherwise conv_wgrad + channel_sum."""
+def token_wgrad(x: torch.Tensor, dy: torch.Tensor, K: int, N: int, want_bias: bool = True):
+    """(dw (N, K), db (N,) or None) fp32 of a linear layer over tokens, bfloat16 operands: x (..., ldx) and
+    dy (..., lddy) channels-last with equally spaced token rows."""
+    M = x.numel() // x.shape[-1]
+    lib = _lib.load()
+    need = lib.unetk_token_wgrad_workspace_bytes(M, K, N)
+    workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
+    dw = torch.empty((N, K), dtype=torch.float32, device=x.device)
+    db = torch.empty((N,), dtype=torch.float32, device=x.device) if want_bias else None
+    call("unetk_token_wgrad", ptr(x), x.stride(-2), ptr(dy), dy.stride(-2), ptr(dw), ptr(db), M, K, N,
+         dtype_code(x.dtype), ptr(workspace), need, 0, stream())
+    return dw, db
+
+
+def token_wgrad_supported(x: torch.Tensor, dy: torch.Tensor, K: int, N: int) -> bool:
+    if x.dtype != torch.bfloat16 or x.stride(-1) != 1 or dy.stride(-1) != 1:
+        return False
+    M = x.numel() // x.shape[-1]
+    return bool(_lib.load().unetk_token_wgrad_supported(M, K, N, dtype_code(x.dtype)))
+
+
+# dw tiles of the token weight-gradient GEMM are 128 x 128: from this many padded elements of dw on it beats
+# the sliced 1x1 form of the convolution weight-gradient kernel (measured on the Swin shapes at batch 64)
+_TOKEN_WGRAD_MIN_ELEMS = 196608
+
+
+def linear_wgrad(x: torch.Tensor, dy: torch.Tensor, Ci: int, Co: int, want_bias: bool = True):
+    """(dw (Co,Ci), db (Co,) or None) fp32 of a linear layer over tokens: x (..., ldx) and dy (..., lddy)
+    channels-last.  bfloat16: the token weight-gradient GEMM for large dw, else the 1x1 form of the convolution
+    weight gradient (whose bias sums ride on the same pass); float32: conv_wgrad + channel_sum."""
     dt = x.dtype
-    if dt != torch.bfloat16 or pad_channels(Ci, dt) != Ci or pad_channels(Co, dt) != Co:
-        return conv_wgrad(x, dy, Ci, Co, 1).view(Co, Ci), channel_sum(dy, Co)
+    if token_wgrad_supported(x, dy, Ci, Co):
+        pad = (-(-Co // 128) * 128) * (-(-Ci // 128) * 128)
+        if pad >= _TOKEN_WGRAD_MIN_ELEMS:
+            return token_wgrad(x, dy, Ci, Co, want_bias)
+    if dt != torch.bfloat16 or pad_channels(Ci, dt) != Ci or pad_channels(Co, dt) != Co or not want_bias:
+        return conv_wgrad(x, dy, Ci, Co, 1).view(Co, Ci), (channel_sum(dy, Co) if want_bias else None)
     ntok = x.numel() // x.shape[-1]
     need = _lib.load().unetk_linear_wgrad_workspace_bytes(ntok, Ci, Co, dtype_code(dt))
     workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
@@ -324,7 +355,8 @@ def maxpool2x2(a):
 
 def bn_act_bwd(g, y, scale, shift, mean, invstd, keep=None, relu=True, dgamma=None, dbeta=None,
                accumulate=False):
-    """Returns (dy, dgamma, dbeta)."""
+    """Returns (dy, dgamma, dbeta).  ``g`` is the gradient of the activation, or a pair (gpix (B,H,W) fp32,
+    gchan (C,) fp32) standing for the rank-one gradient gpix[b,y,x] * gchan[c] that is never materialised."""
     B, H, W, C = y.shape
     dev = y.device
     dy = torch.empty_like(y)
@@ -335,6 +367,14 @@ def bn_act_bwd(g, y, scale, shift, mean, invstd, keep=None, relu=True, dgamma=No
         dgamma = torch.empty(C, dtype=torch.float32, device=dev)
         dbeta = torch.empty(C, dtype=torch.float32, device=dev)
         accumulate = False
+    if isinstance(g, tuple):
+        gpix, gchan = g
+        if gchan.numel() < C:       # channel padding of the activation: the padded channels get no gradient
+            gchan = torch.cat([gchan, gchan.new_zeros(C - gchan.numel())])
+        call("unetk_bn_act_bwd_rank1", ptr(gpix), ptr(gchan), ptr(y), ptr(dy), B, H, W, C, ptr(scale), ptr(shift),
+             ptr(mean), ptr(invstd), ptr(keep), 1 if relu else 0, ptr(dgamma), ptr(dbeta), 1 if accumulate else 0,
+             ptr(partials), ptr(sums), dtype_code(y.dtype), stream())
+        return dy, dgamma, dbeta
     call("unetk_bn_act_bwd", ptr(g), ptr(y), ptr(dy), B, H, W, C, ptr(scale), ptr(shift), ptr(mean),
          ptr(invstd), ptr(keep), 1 if relu else 0, ptr(dgamma), ptr(dbeta), 1 if accumulate else 0,
          ptr(partials), ptr(sums), dtype_code(y.dtype), stream())

@@ -258,11 +258,10 @@ def _linear(x, w, b, cx, act=0, resid=None, keep=None, out=None, out2=False):
 
 def _linear_bwd(x, dy, w, cx, grads, wname, bname, need_dx=True, gelu_grad_of=None):
     Co, Ci = w.shape[0], w.shape[1]
+    dw, db = ops.linear_wgrad(x, dy, Ci, Co, want_bias=bname is not None)
     if bname is not None:
-        dw, grads[bname] = ops.linear_wgrad(x, dy, Ci, Co)
-        grads[wname] = dw.view(w.shape)
-    else:
-        grads[wname] = ops.conv_wgrad(x, dy, Ci, Co, 1).view(w.shape)
+        grads[bname] = db
+    grads[wname] = dw.view(w.shape)
     if need_dx:
         return _linear_launch(dy, cx.packed(w.view(Co, Ci), transpose=True), gelu_grad_of=gelu_grad_of)
     return None
@@ -408,7 +407,7 @@ def _decoder_head_bwd(dec, pre, ctx, dcat, cx, grads):
     dtmp = torch.empty((B, h, w, 4 * up), dtype=cx.dt, device=x.device)
     ops.pixel_shuffle(dtmp, dcat, None, up, backward=True)
     grads[pre + "upsample.bias"] = ops.channel_sum(dcat, up)
-    dw2 = ops.conv_wgrad(x, dtmp, Cin, 4 * up, 1).view(2, 2, up, Cin)
+    dw2 = ops.linear_wgrad(x, dtmp, Cin, 4 * up, want_bias=False)[0].view(2, 2, up, Cin)
     grads[pre + "upsample.weight"] = dw2.permute(3, 2, 0, 1).contiguous()
     dx = _linear_launch(dtmp, ops.PackedConv(w2.contiguous(), cx.dt, transpose=True))
     dskip = None
@@ -417,7 +416,7 @@ def _decoder_head_bwd(dec, pre, ctx, dcat, cx, grads):
         dsp = dcat[..., up:]
         if resized is not None:
             dsp = ops.upsample_bwd(dsp.contiguous(), up, resized[0], resized[1])
-        grads[pre + "skip_projection.weight"] = ops.conv_wgrad(skip, dsp, wsk.shape[1], up, 1).view(wsk.shape)
+        grads[pre + "skip_projection.weight"] = ops.linear_wgrad(skip, dsp, wsk.shape[1], up, want_bias=False)[0].view(wsk.shape)
         dskip = _linear_launch(dsp, cx.packed(wsk, transpose=True))
     return dx, dskip
 

@@ -273,8 +273,15 @@ class _UNetTrainFn(torch.autograd.Function):
         side = _side_stream(dout.device) if (OVERLAP_WGRAD and model.grad_sink is None) else main
         held = []          # operands of side-stream kernels stay allocated until the join
 
-        # final 1x1 conv
-        g, dw, db = ops.head1x1_bwd(saved["head_in"], model.conv.weight, dout)
+        # final 1x1 conv.  With one output channel the gradient of its input is the outer product
+        # dout[pixel] * w[channel]: it is handed to the BatchNorm backward of the last block as its two
+        # factors and never written (a (B,H,W,C) tensor written once and read twice otherwise).
+        if model.conv.out_channels == 1:
+            _, dw, db = ops.head1x1_bwd(saved["head_in"], model.conv.weight, dout, need_dx=False)
+            g = (dout.detach().contiguous().float().view(dout.shape[0], dout.shape[2], dout.shape[3]),
+                 model.conv.weight.detach().reshape(-1).float().contiguous())
+        else:
+            g, dw, db = ops.head1x1_bwd(saved["head_in"], model.conv.weight, dout)
         grads["conv.weight"], grads["conv.bias"] = dw, db
 
         def block_bwd(name, g, need_dx=True, split=0):
