@@ -34,15 +34,12 @@ for side, C in ((64, 96), (32, 192), (16, 384), (8, 768)):
         ga = timeit(lambda: ops.linear_fwd(dy, pwt, gelu_grad_of=x)) if ops.linear_supported(dy, pwt) else float("nan")
         tot[3] += gf; tot[4] += gd
         tw = timeit(lambda: ops.conv_wgrad(x, dy, ci, co, 1, workspace=ws))
-        os.environ["UNETK_WG_WM"] = "2"
         tg = timeit(lambda: ops.token_wgrad(x, dy, ci, co))
-        os.environ["UNETK_WG_WM"] = "4"
-        tg4 = timeit(lambda: ops.token_wgrad(x, dy, ci, co))
         M = B * side * side
         fl = 2.0 * M * ci * co
         by = 2.0 * M * (ci + co)
         tot[0] += tf; tot[1] += td; tot[2] += tw; tot[5] += tg
         print(f"{side:3d}^2 {name:5s} {ci:5d}->{co:5d}  GEMM fwd {gf*1e3:6.1f} us {fl/gf/1e9:5.0f} TF/s {by/gf/1e9:5.2f} TB/s dgrad {gd*1e3:6.1f} | gelu2 {gg*1e3:6.1f} gelu' {ga*1e3:6.1f} || conv1x1 fwd {tf*1e3:7.1f} us {fl/tf/1e9:6.0f} TF/s {by/tf/1e9:5.2f} TB/s | "
-              f"dgrad {td*1e3:7.1f} us {fl/td/1e9:6.0f} TF/s | wgrad {tw*1e3:7.1f} us {fl/tw/1e9:6.0f} TF/s {by/tw/1e9:5.2f} TB/s | NEW wgrad {tg*1e3:7.1f} us {fl/tg/1e9:6.0f} TF/s | wm4 {tg4*1e3:7.1f} us {fl/tg4/1e9:6.0f} TF/s", flush=True)
+              f"dgrad {td*1e3:7.1f} us {fl/td/1e9:6.0f} TF/s | wgrad {tw*1e3:7.1f} us {fl/tw/1e9:6.0f} TF/s {by/tw/1e9:5.2f} TB/s | NEW wgrad {tg*1e3:7.1f} us {fl/tg/1e9:6.0f} TF/s ", flush=True)
 print("token_wgrad sum ms", round(tot[5], 3))
 print("sum ms", [round(t, 3) for t in tot])

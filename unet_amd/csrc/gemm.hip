@@ -27,8 +27,6 @@
 //
 // Weights arrive in the packed layout of the convolution kernels for kernel size 1,
 // [N/BN][K/32][BN][32]: a stage's weight slab is one contiguous run.
-#include <stdlib.h>
-
 #include "common.h"
 #include "mma.h"
 
@@ -467,30 +465,34 @@ __global__ __launch_bounds__(256) void lin_wgrad_reduce_kernel(const float* __re
 }
 
 struct WgPlan {
-  int wm, N_pad, K_pad, gn, gk, nsplit, chunk;
+  int N_pad, K_pad, gn, gk, nsplit, chunk;
 };
 
 inline WgPlan plan_lin_wgrad(long M, int K, int N) {
   WgPlan p;
-  // 256 x 128 tiles (8 waves, one workgroup per CU) where dw is large enough to fill the chip with them
-  // and deep enough in tokens; else 128 x 128 (4 waves, three per CU)
-  p.wm = 2;
-  if (const char* e = getenv("UNETK_WG_WM")) p.wm = atoi(e) == 4 ? 4 : 2;
-  const int bn = 64 * p.wm, bk = 128;
+  const int bn = 128, bk = 128;
   p.N_pad = cdiv(N, bn) * bn;
   p.K_pad = cdiv(K, bk) * bk;
   p.gn = p.N_pad / bn;
   p.gk = p.K_pad / bk;
   const long tiles = (long)p.gn * p.gk;
-  const long slots = p.wm == 4 ? 256L : 256L * 3;
-  long s = (slots + tiles - 1) / tiles;
-  long smax = (M + 255) / 256;                  // at least 8 stages of 32 tokens per workgroup
-  if (smax > 256) smax = 256;                   // ... and at most 256 partial tiles per tile of dw
-  if (s > smax) s = smax;
-  if (s < 1) s = 1;
-  if (s >= 8) s = (s + 7) / 8 * 8;              // multiples of 8 enable the XCD-aware order
-  p.nsplit = (int)s;
-  p.chunk = (int)(((M + s - 1) / s + 31) / 32 * 32);
+  // Token split: more ranges = more workgroups in flight and fewer stages each, but every range costs one
+  // more fp32 copy of dw written and read back.  Pick the count with the lowest modelled time
+  // (0.5 us per 32-token stage at three workgroups per CU, 3 TB/s for the slabs; measured on MI355X).
+  const double stages = (double)((M + 31) / 32);
+  const double slab_us = 2.0 * 4.0 * p.N_pad * p.K_pad / 3.0e6;
+  long best_s = 1;
+  double best = 1e30;
+  for (long s = 1; s <= 256 && s * 256 <= M + 255; s += (s < 8 ? 1 : 8)) {
+    const double rounds = (double)((tiles * s + 767) / 768);
+    const double t = stages / s * 0.5 * rounds + slab_us * s;
+    if (t < best) {
+      best = t;
+      best_s = s;
+    }
+  }
+  p.nsplit = (int)best_s;
+  p.chunk = (int)(((M + best_s - 1) / best_s + 31) / 32 * 32);
   return p;
 }
 
@@ -584,8 +586,8 @@ int unetk_token_wgrad(const void* x, int ldx, const void* dy, int lddy, float* d
   a.ldx = ldx; a.lddy = lddy; a.M = (int)M; a.N = N; a.K = K; a.N_pad = p.N_pad; a.K_pad = p.K_pad;
   a.nsplit = p.nsplit; a.chunk = p.chunk; a.gn = p.gn; a.gk = p.gk;
   const unsigned grid = (unsigned)(p.gn * p.gk * p.nsplit);
-  if (p.wm == 4) hipLaunchKernelGGL((lin_wgrad_kernel<4, 2, 5>), dim3(grid), dim3(512), 0, stream, a);
-  else hipLaunchKernelGGL((lin_wgrad_kernel<2, 2, 3>), dim3(grid), dim3(256), 0, stream, a);
+  // (256 x 128 tiles with eight waves and a five-stage ring measured slower on every Swin shape)
+  hipLaunchKernelGGL((lin_wgrad_kernel<2, 2, 3>), dim3(grid), dim3(256), 0, stream, a);
   UNETK_CHECK_LAUNCH();
   const int nmain = cdiv((long)N * (K / 4), 64);
   hipLaunchKernelGGL(lin_wgrad_reduce_kernel, dim3((unsigned)(nmain + (dbias ? cdiv(N, 256) : 0))), dim3(256), 0, stream,
