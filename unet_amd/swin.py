@@ -10,6 +10,7 @@ the UNet.  Window size 8 and head dimension 32 (every stage of the reference con
 the attention kernel implements; other values raise ValueError.
 """
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -205,10 +206,12 @@ class _Ctx:
     for training the data-gradient form) and looked up by the parameter's address; anything not
     found there (a reshaped copy) is packed on the spot.  Owned by the autograd node of the step
     (or dropped after an inference call): interleaved models or steps cannot see each other's packs."""
-    __slots__ = ("dt", "pool")
+    __slots__ = ("dt", "pool", "side", "held")
 
     def __init__(self, model, training):
         self.dt = dt = model.compute_dtype
+        self.side = None        # set by the backward pass: the stream the weight gradients run on
+        self.held = []
         ws = []
         for m in model.modules():
             if isinstance(m, (nn.Linear, nn.Conv2d)):
@@ -235,6 +238,44 @@ class _Ctx:
         return ops.PackedConv(w, self.dt, transpose=transpose)
 
 
+# Weight gradients are off the critical chain of the backward pass (data gradient -> norm backward ->
+# data gradient ...).  The Swin encoder's late stages launch many small kernels (512-768 workgroups, one
+# round of the chip or less): run on a second HIP stream, their weight gradients fill the CUs the
+# chain leaves idle at every kernel's ramp-up and tail.  Off with a data-parallel gradient sink
+# (the sink copies each gradient on the main stream as soon as it is produced).
+OVERLAP_WGRAD = os.environ.get("UNETK_SWIN_OVERLAP_WGRAD", "1") != "0"
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = torch.device(device).index
+    if key is None:
+        key = torch.cuda.current_device()
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+    return st
+
+
+def _on_side(cx, fn, *operands):
+    """Runs fn() (weight-gradient launches reading ``operands``) on the side stream, after everything queued
+    so far on the current stream; the operands stay allocated until the streams are joined.  Returns fn()'s
+    result, whose tensors are marked as used by the main stream too."""
+    if cx.side is None:
+        return fn()
+    main = torch.cuda.current_stream()
+    ready = torch.cuda.Event()
+    ready.record(main)
+    cx.held.append(operands)
+    with torch.cuda.stream(cx.side):
+        cx.side.wait_event(ready)
+        res = fn()
+    for t in (res if isinstance(res, tuple) else (res,)):
+        if t is not None:
+            t.record_stream(main)
+    return res
+
+
 def _linear_launch(x, pw, shift=None, act=0, resid=None, resid_keep=None, out=None, out2=False, gelu_grad_of=None):
     """Every token-linear GEMM launch (forward and data gradient) goes through here: the GEMM kernel
     where it applies (bfloat16, regular shapes), else the 1x1 form of the convolution kernel with the
@@ -258,7 +299,7 @@ def _linear(x, w, b, cx, act=0, resid=None, keep=None, out=None, out2=False):
 
 def _linear_bwd(x, dy, w, cx, grads, wname, bname, need_dx=True, gelu_grad_of=None):
     Co, Ci = w.shape[0], w.shape[1]
-    dw, db = ops.linear_wgrad(x, dy, Ci, Co, want_bias=bname is not None)
+    dw, db = _on_side(cx, lambda: ops.linear_wgrad(x, dy, Ci, Co, want_bias=bname is not None), x, dy)
     if bname is not None:
         grads[bname] = db
     grads[wname] = dw.view(w.shape)
@@ -366,7 +407,7 @@ def _conv_bn_relu_bwd(conv, bn, tag, ctx, g, cx, grads, need_dx=True):
     dy, dgamma, dbeta = ops.bn_act_bwd(g, y, sc, sh, mean, invstd, None, relu=True)
     cname, bname = tag
     grads[bname + ".weight"], grads[bname + ".bias"] = dgamma, dbeta
-    grads[cname + ".weight"] = ops.conv_wgrad(t, dy, conv.in_channels, conv.out_channels, 3)
+    grads[cname + ".weight"] = _on_side(cx, lambda: ops.conv_wgrad(t, dy, conv.in_channels, conv.out_channels, 3), t, dy)
     if conv.bias is not None:
         grads[cname + ".bias"] = torch.zeros_like(conv.bias)      # exactly 0 in front of BatchNorm
     if need_dx:
@@ -407,8 +448,9 @@ def _decoder_head_bwd(dec, pre, ctx, dcat, cx, grads):
     dtmp = torch.empty((B, h, w, 4 * up), dtype=cx.dt, device=x.device)
     ops.pixel_shuffle(dtmp, dcat, None, up, backward=True)
     grads[pre + "upsample.bias"] = ops.channel_sum(dcat, up)
-    dw2 = ops.linear_wgrad(x, dtmp, Cin, 4 * up, want_bias=False)[0].view(2, 2, up, Cin)
-    grads[pre + "upsample.weight"] = dw2.permute(3, 2, 0, 1).contiguous()
+    grads[pre + "upsample.weight"] = _on_side(
+        cx, lambda: ops.linear_wgrad(x, dtmp, Cin, 4 * up, want_bias=False)[0].view(2, 2, up, Cin)
+        .permute(3, 2, 0, 1).contiguous(), x, dtmp)
     dx = _linear_launch(dtmp, ops.PackedConv(w2.contiguous(), cx.dt, transpose=True))
     dskip = None
     if skip is not None and dec.skip_projection is not None:
@@ -416,7 +458,8 @@ def _decoder_head_bwd(dec, pre, ctx, dcat, cx, grads):
         dsp = dcat[..., up:]
         if resized is not None:
             dsp = ops.upsample_bwd(dsp.contiguous(), up, resized[0], resized[1])
-        grads[pre + "skip_projection.weight"] = ops.linear_wgrad(skip, dsp, wsk.shape[1], up, want_bias=False)[0].view(wsk.shape)
+        grads[pre + "skip_projection.weight"] = _on_side(
+            cx, lambda: ops.linear_wgrad(skip, dsp, wsk.shape[1], up, want_bias=False)[0], skip, dsp).view(wsk.shape)
         dskip = _linear_launch(dsp, cx.packed(wsk, transpose=True))
     return dx, dskip
 
@@ -484,6 +527,8 @@ class _SwinTrainFn(torch.autograd.Function):
                                "by the first backward (run the forward again)")
         cx = save[0][1]                 # dtype and the packs made by this step's forward
         grads = ops.GradOut(model.grad_sink)
+        main = torch.cuda.current_stream()
+        cx.side = _side_stream(dout.device) if (OVERLAP_WGRAD and model.grad_sink is None) else None
         nl = model.num_layers
         dskips: Dict[int, torch.Tensor] = {}
         g = None
@@ -532,6 +577,10 @@ class _SwinTrainFn(torch.autograd.Function):
                     dtok = _linear_launch(dt0, cx.packed(wpe, transpose=True))
                     B, Cin, H, W = ctx.in_shape
                     g = ops.unpatchify(dtok, Cin, H, W, model.patch_size_val)
+        if cx.side is not None:
+            main.wait_stream(cx.side)
+            cx.side = None
+        cx.held.clear()
         ctx.save = None
         outg = [grads.get(n) if p.requires_grad else None for n, p in model.named_parameters()]
         return (g if ctx.need_dx else None, None, None, *outg)
