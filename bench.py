@@ -59,6 +59,9 @@ def parse(argv=None):
                     help="all: headline UNet step with the swin and predict records attached; or one of them alone")
     ap.add_argument("--grid", type=int, default=8192, help="predict: side of the synthetic grid")
     ap.add_argument("--swin-batch", type=int, default=64)
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay the training step as one HIP graph (auto: the Swin step on one rank)")
+    ap.add_argument("--no-small-batch", action="store_true", help="swin: skip the batch-6 graph/eager comparison")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args(argv)
@@ -239,7 +242,8 @@ def run_train(args, rank, world, dev, dt):
         from unet_amd.dist import GradReducer
         reducer = GradReducer(model)
     # the trainer's optimizer tail (enhanced_training_multi_loss.py:758-763, 827-829)
-    opt = FusedAdamW(model.parameters(), lr=5e-5, weight_decay=5e-5, max_grad_norm=1.0)
+    graphed = args.graph == "on" and world == 1
+    opt = FusedAdamW(model.parameters(), lr=5e-5, weight_decay=5e-5, max_grad_norm=1.0, capturable=graphed)
 
     def step():
         for p in model.parameters():
@@ -250,9 +254,13 @@ def run_train(args, rank, world, dev, dt):
             reducer.finish()
         opt.step()
 
+    if graphed:
+        from unet_amd.graph import GraphedTrainStep
+        gstep = GraphedTrainStep(model, crit, opt, x, y, w)
+        step = lambda: gstep(x, y, w)
     for _ in range(args.warmup):
         step()
-    timer = ConvTimer() if (rank == 0 and not args.no_roofline) else None
+    timer = ConvTimer() if (rank == 0 and not args.no_roofline and not graphed) else None
     if timer is not None:
         timer.__enter__()
     el = timed(step, args.steps, 0, world, dev)
@@ -303,6 +311,9 @@ def cpu_baseline_train(batch, size):
 
 
 # ---------------------------------------------------------------------------- Swin-UNet training step
+GRAPH_MAX_BATCH = 16
+
+
 def run_swin(args, rank, world, dev, dt):
     """BASELINE config 3 as swin_unet_model.py:809-823 runs it."""
     from oracle import swin_oracle
@@ -323,36 +334,56 @@ def run_swin(args, rank, world, dev, dt):
     if world > 1:
         from unet_amd.dist import GradReducer
         reducer = GradReducer(model)
-    opt = FusedAdamW(model.parameters(), lr=1e-4, weight_decay=0.05, max_grad_norm=1.0)
+    # Small batches on one rank: the whole step is captured into a HIP graph and replayed (the ~600 launches of
+    # a step cost the host ~13 ms, more than the GPU needs below ~32 patches; measured 6.3 ms graphed vs 14.4 ms
+    # eager at the reference's batch of 6, but 16.2 vs 15.7 ms at batch 64, where the GPU is the limit and the
+    # graph's per-node dispatch costs more than eager launches that run ahead).  Several ranks: eager, the bucket
+    # all-reduces start from inside the backward pass.
+    graphed = args.graph == "on" or (args.graph == "auto" and world == 1 and B <= GRAPH_MAX_BATCH)
+    opt = FusedAdamW(model.parameters(), lr=1e-4, weight_decay=0.05, max_grad_norm=1.0, capturable=graphed)
 
-    def step():
+    def resize(out, labels):
+        return ops.interpolate_bilinear(out, labels.shape[-2:]) if out.shape[-2:] != labels.shape[-2:] else out
+
+    def eager_step():
         for p in model.parameters():
             p.grad = None
-        out = model(x)
-        if out.shape[-2:] != y.shape[-2:]:
-            out = ops.interpolate_bilinear(out, y.shape[-2:])
-        loss, _ = crit(out, y, w)
+        loss, _ = crit(resize(model(x), y), y, w)
         loss.backward()
         if reducer is not None:
             reducer.finish()
         opt.step()
 
+    step = eager_step
+    if graphed:
+        if reducer is not None:
+            raise SystemExit("--graph on: the captured step has no gradient all-reduce; use one rank")
+        from unet_amd.graph import GraphedTrainStep
+        gstep = GraphedTrainStep(model, crit, opt, x, y, w, post=resize)
+        step = lambda: gstep(x, y, w)      # copies the batch into the captured buffers, then one graph launch
+
     for _ in range(args.warmup):
         step()
     # The step queues ~600 small launches: two events around each of the 117 linear launches of EVERY timed
     # step would slow the host enough to show in the step time, so only the last timed step carries them.
+    # (A replayed graph has no per-launch host code to hang events on: there the events come from one
+    # eager step run after the timed region.)
     timer = LinearTimer() if (rank == 0 and not args.no_roofline) else None
     calls = {"n": 0}
 
     def timed_step():
         calls["n"] += 1
-        if timer is not None and calls["n"] == args.steps:
+        if timer is not None and not graphed and calls["n"] == args.steps:
             with timer:
                 step()
         else:
             step()
 
     el = timed(timed_step, args.steps, 0, world, dev)
+    if timer is not None and graphed:
+        with timer:
+            eager_step()
+        torch.cuda.synchronize()
     ms = el / args.steps * 1e3
     rec = None
     if rank == 0:
@@ -367,12 +398,24 @@ def run_swin(args, rank, world, dev, dt):
             "config": {"workload": f"SwinUNet (embed 96, depths 2-2-6-2, window 8) trainer step: fwd + bilinear x2 to the "
                                    f"label + loss(tid_gradient) + bwd + clip + AdamW(1e-4, 0.05), batch {B}/GPU of "
                                    f"4x{args.size}x{args.size}", "global_batch": world * B,
+                       "launch": "one HIP graph per step" if graphed else "eager",
                        "parallelism": f"dp{world}" if world > 1 else "single"},
             "roofline": roof, "cpu_baseline": cpu}
     if reducer is not None:
         reducer.detach()
     del model, opt, crit, x, y, w
     torch.cuda.empty_cache()
+    if rec is not None and world == 1 and args.graph == "auto" and B > GRAPH_MAX_BATCH and not args.no_small_batch:
+        # the reference trainer's own batch size (swin_unet_model.py:728), where the step is launch-bound
+        import copy
+        small = copy.copy(args)
+        small.swin_batch, small.no_roofline, small.no_cpu_baseline, small.steps = 6, True, True, max(args.steps, 10)
+        rows = {}
+        for mode in ("on", "off"):
+            small.graph = mode
+            r = run_swin(small, rank, world, dev, dt)
+            rows["graph_ms_per_step" if mode == "on" else "eager_ms_per_step"] = r["ms_per_step"]
+        rec["reference_batch"] = dict(batch=6, patches_per_s=round(6e3 / rows["graph_ms_per_step"], 1), **rows)
     return rec
 
 

@@ -295,6 +295,15 @@ int unetk_adamw_step(float* const* params, float* const* grads, float* const* m,
                      double beta2, double eps, double weight_decay, int64_t step, const float* clip_coef,
                      int write_grad, unetk_stream_t stream);
 
+/* unetk_adamw_step for a step that is captured into a HIP graph and replayed: nothing that changes from step
+ * to step may be a launch argument, so the step number and the learning rate live on the device.
+ * hyper (5 doubles, device): {steps taken so far, lr, weight_decay, beta1, beta2}; each call adds one to
+ * hyper[0] and derives the step's scalars into dyn (3 floats of device scratch) before the update. */
+int unetk_adamw_step_device(float* const* params, float* const* grads, float* const* m, float* const* v,
+                            const int64_t* sizes, const int32_t* chunks, int nchunks, double* hyper, float* dyn,
+                            double eps, const float* clip_coef, int write_grad, double beta1, double beta2,
+                            unetk_stream_t stream);
+
 /* ---- training-patch extraction -------------------------------------------------------
  * EnhancedDataPreparation.extract_patches, enhanced_training_multi_loss.py:633-720: candidate
  * windows start at margin + k*S (margin = P/8) while start + P + margin <= size, row-major.

@@ -52,6 +52,7 @@ _SIGNATURES = {
     "unetk_grad_norm": (I, [P, P, P, I, F, P, P, P]),
     "unetk_scale_list": (I, [P, P, P, I, P, P]),
     "unetk_adamw_step": (I, [P, P, P, P, P, P, I, D, D, D, D, D, L, P, I, P]),
+    "unetk_adamw_step_device": (I, [P, P, P, P, P, P, I, P, P, D, P, I, D, D, P]),
     "unetk_patch_qc": (I, [P, I, P, P, I, I, I, I, D, P, P]),
     "unetk_patch_gather": (I, [P, I, P, P, I, I, P, P, I, I, I, P, P, P, P]),
     "unetk_metrics_num_partials": (I, [L]),

@@ -78,6 +78,7 @@ struct AdamArgs {
   const int64_t* sizes;
   const int32_t* chunks;
   const float* coef;      // device clip coefficient or null
+  const float* dyn;       // device {decay, step_size, bc2_sqrt} (graph-replayable step) or null: the values below
   float decay, omb1, beta2, omb2, eps, step_size, bc2_sqrt;   // derived in double on the host
   int write_grad;
 };
@@ -95,21 +96,36 @@ __global__ __launch_bounds__(OPT_THREADS) void adamw_kernel(AdamArgs a) {
   const int64_t beg = (int64_t)c * OPT_CHUNK;
   const int64_t end = beg + OPT_CHUNK < n ? beg + OPT_CHUNK : n;
   const float k = a.coef ? a.coef[0] : 1.f;
+  const float decay = a.dyn ? a.dyn[0] : a.decay;
+  const float step_size = a.dyn ? a.dyn[1] : a.step_size;
+  const float bc2_sqrt = a.dyn ? a.dyn[2] : a.bc2_sqrt;
   for (int64_t i = beg + threadIdx.x; i < end; i += OPT_THREADS) {
     float gi = g[i];
     if (k != 1.f) {
       gi *= k;
       if (a.write_grad) g[i] = gi;
     }
-    float pi = p[i] * a.decay;
+    float pi = p[i] * decay;
     const float mi = m[i] + (gi - m[i]) * a.omb1;
     const float vi = v[i] * a.beta2 + a.omb2 * gi * gi;
-    const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
-    pi -= a.step_size * (mi / denom);
+    const float denom = sqrtf(vi) / bc2_sqrt + a.eps;
+    pi -= step_size * (mi / denom);
     p[i] = pi;
     m[i] = mi;
     v[i] = vi;
   }
+}
+
+// One thread: advances the step counter kept on the device and derives the step's scalars from it, in
+// double as the host path does.  hyper: {step, lr, weight_decay, beta1, beta2}; dyn: {decay, step_size, bc2_sqrt}.
+__global__ void adamw_advance_kernel(double* __restrict__ hyper, float* __restrict__ dyn) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double step = hyper[0] + 1.0;
+  hyper[0] = step;
+  const double lr = hyper[1], wd = hyper[2], b1 = hyper[3], b2 = hyper[4];
+  dyn[0] = (float)(1.0 - lr * wd);
+  dyn[1] = (float)(lr / (1.0 - pow(b1, step)));
+  dyn[2] = (float)sqrt(1.0 - pow(b2, step));
 }
 
 }  // namespace
@@ -150,6 +166,29 @@ int unetk_adamw_step(float* const* params, float* const* grads, float* const* m,
   a.eps = (float)eps;
   a.step_size = (float)(lr / (1.0 - pow(beta1, (double)step)));
   a.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+  a.write_grad = write_grad;
+  a.dyn = nullptr;
+  hipLaunchKernelGGL(adamw_kernel, dim3(nchunks), dim3(OPT_THREADS), 0, stream, a);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_adamw_step_device(float* const* params, float* const* grads, float* const* m, float* const* v,
+                            const int64_t* sizes, const int32_t* chunks, int nchunks, double* hyper, float* dyn,
+                            double eps, const float* clip_coef, int write_grad, double beta1, double beta2,
+                            hipStream_t stream) {
+  UNETK_CHECK_ARG(params && grads && m && v && sizes && chunks && nchunks > 0 && hyper && dyn,
+                  "adamw_step_device: bad arguments");
+  hipLaunchKernelGGL(adamw_advance_kernel, dim3(1), dim3(64), 0, stream, hyper, dyn);
+  UNETK_CHECK_LAUNCH();
+  AdamArgs a;
+  a.params = params; a.grads = grads; a.m = m; a.v = v; a.sizes = sizes; a.chunks = chunks; a.coef = clip_coef;
+  a.dyn = dyn;
+  a.decay = 1.f; a.step_size = 0.f; a.bc2_sqrt = 1.f;
+  a.omb1 = (float)(1.0 - beta1);
+  a.beta2 = (float)beta2;
+  a.omb2 = (float)(1.0 - beta2);
+  a.eps = (float)eps;
   a.write_grad = write_grad;
   hipLaunchKernelGGL(adamw_kernel, dim3(nchunks), dim3(OPT_THREADS), 0, stream, a);
   UNETK_CHECK_LAUNCH();

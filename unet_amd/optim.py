@@ -89,13 +89,81 @@ class FusedAdamW(torch.optim.Optimizer):
     """
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
-                 max_grad_norm: Optional[float] = None):
+                 max_grad_norm: Optional[float] = None, capturable: bool = False):
+        """``capturable``: the step number and the learning rate are kept on the device, so that a step
+        captured into a HIP graph (``unet_amd.graph.GraphedTrainStep``) replays correctly; a learning rate
+        changed by a scheduler reaches the device through ``sync_hyper()``."""
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
             raise ValueError("invalid AdamW hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.max_grad_norm = max_grad_norm
         self.last_grad_norm = None
+        self.capturable = capturable
         self._lists = {}
+        self._hyper = {}        # group index -> (hyper double[5] on the device, dyn float[3], last pushed (lr, wd, betas))
+
+    # ------------------------------------------------------------------ device-resident step / lr (capturable)
+    def _hyper_for(self, gi, group, device):
+        hit = self._hyper.get(gi)
+        if hit is None:
+            b1, b2 = group["betas"]
+            step0 = 0.0
+            for p in group["params"]:
+                st = self.state.get(p)
+                if st:
+                    step0 = float(st["step"])
+                    break
+            hyper = torch.tensor([step0, group["lr"], group["weight_decay"], b1, b2], dtype=torch.float64, device=device)
+            dyn = torch.zeros(3, dtype=torch.float32, device=device)
+            hit = self._hyper[gi] = [hyper, dyn, (group["lr"], group["weight_decay"], b1, b2)]
+        return hit
+
+    def sync_hyper(self):
+        """Pushes learning rates / decays changed on the host (a scheduler) to the device copies."""
+        for gi, group in enumerate(self.param_groups):
+            hit = self._hyper.get(gi)
+            if hit is None:
+                continue
+            now = (group["lr"], group["weight_decay"], group["betas"][0], group["betas"][1])
+            if now != hit[2]:
+                hit[0][1:].copy_(torch.tensor(now, dtype=torch.float64), non_blocking=False)
+                hit[2] = now
+
+    def snapshot(self):
+        """Copies of the moments and step counts, for ``restore`` (a graph capture's warm-up steps are undone)."""
+        snap = {}
+        for group in self.param_groups:
+            for p in group["params"]:
+                st = self.state.get(p)
+                if st:
+                    snap[p] = {k: v.clone() for k, v in st.items()}
+        return snap, {gi: h[0][0:1].clone() for gi, h in self._hyper.items()}
+
+    @torch.no_grad()
+    def restore(self, snap):
+        """Puts the optimizer state back in place (same tensors, old contents; state that did not exist at the
+        snapshot returns to zero)."""
+        states, steps = snap
+        for group in self.param_groups:
+            for p in group["params"]:
+                st = self.state.get(p)
+                if not st:
+                    continue
+                old = states.get(p)
+                for k, v in st.items():
+                    if old is not None:
+                        v.copy_(old[k])
+                    else:
+                        v.zero_()
+        for gi, h in self._hyper.items():
+            if gi in steps:
+                h[0][0:1].copy_(steps[gi])
+            else:
+                h[0][0:1].zero_()
+
+    def device_step_count(self, gi=0):
+        hit = self._hyper.get(gi)
+        return None if hit is None else int(hit[0][0].item())
 
     def _list_for(self, key, tensors):
         sig = tuple(t.numel() for t in tensors)
@@ -145,6 +213,13 @@ class FusedAdamW(torch.optim.Optimizer):
             pp, gp = tl.pointers(params, "p"), tl.pointers(grads, "g")
             mp = tl.pointers([self.state[p]["exp_avg"] for p in params], "m")
             vp = tl.pointers([self.state[p]["exp_avg_sq"] for p in params], "v")
+            if self.capturable:
+                # (the host-side counters above only count the calls made outside graph replays; the device
+                # counter is the truth: device_step_count())
+                hyper, dyn, _ = self._hyper_for(gi, group, tl.device)
+                call("unetk_adamw_step_device", ptr(pp), ptr(gp), ptr(mp), ptr(vp), ptr(tl.sizes), ptr(tl.chunks),
+                     tl.nchunks, ptr(hyper), ptr(dyn), float(group["eps"]), ptr(coef), 1, float(b1), float(b2), stream())
+                continue
             call("unetk_adamw_step", ptr(pp), ptr(gp), ptr(mp), ptr(vp), ptr(tl.sizes), ptr(tl.chunks), tl.nchunks, float(group["lr"]), float(b1), float(b2),
                  float(group["eps"]), float(group["weight_decay"]), step, ptr(coef), 1, stream())
         return loss
