@@ -7,11 +7,14 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/${1:-prof}
 mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_trace -- python3 $R/bench.py --steps 10 --warmup 3 > $O/train_bench.log 2>&1
+# the default command, workload by workload (the same timed regions; one stats file per workload)
+for w in train swin predict; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${w}_trace -- python3 $R/bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline --no-small-batch > $O/${w}_bench.log 2>&1
+done
 for w in train predict swin; do
   extra="--steps 2 --warmup 1 --no-cpu-baseline --no-roofline"
-  [ $w = predict ] && extra="--steps 1 --warmup 0 --no-cpu-baseline --grid 4096"
-  [ $w = swin ] && extra="--steps 2 --warmup 1 --batch 16"
+  [ $w = predict ] && extra="--steps 1 --warmup 0 --no-cpu-baseline --no-roofline --grid 4096"
+  [ $w = swin ] && extra="--steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-small-batch"
   timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${w}_fetch -- python3 $R/bench.py --workload $w $extra > $O/${w}_fetch.log 2>&1
   timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${w}_write -- python3 $R/bench.py --workload $w $extra > $O/${w}_write.log 2>&1
   timeout -s KILL 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/${w}_mfma -- python3 $R/bench.py --workload $w $extra > $O/${w}_mfma.log 2>&1
