@@ -6,4 +6,4 @@ from .predictor import LargeAreaPredictor, LargeAreaPredictionConfig  # noqa: F4
 from .optim import FusedAdamW, clip_grad_norm_  # noqa: F401
 from .data import EnhancedDataPreparation  # noqa: F401
 from .metrics import StreamingMetrics  # noqa: F401
-from . import prep  # noqa: F401
+from . import graph, prep  # noqa: F401
