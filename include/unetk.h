@@ -53,6 +53,10 @@ int unetk_conv_pack_weight(const float* w, void* packed, int Co, int Ci, int ks,
 int unetk_conv_pack_weights(const int64_t* jobs, const int* blocks, int nblocks, void* dst_base, int dtype,
                             unetk_stream_t stream);
 int unetk_conv_num_tiles(int B, int H, int W, int ks);
+/* Rows of batch-statistics partials ([rows][2][Co] floats) that unetk_conv_fwd writes for this problem when it
+ * is given a stats buffer and no residual: one per pixel tile, or one per workgroup where the persistent
+ * kernel for the full-resolution layers (3x3, bf16, 33..48 input and up to 48 output channels) takes it. */
+int unetk_conv_stats_rows(int B, int H, int W, int Ci, int Co, int ks, int bn, int dtype, int ldin, int act);
 /* out = act((conv(in, w)) * ep_scale + ep_shift) [* resid_keep[b] + resid].
  * stats (nullable): [unetk_conv_num_tiles][2][Co] per-tile sum / sum of squares of the raw
  * convolution output (fp32 accumulators), the BatchNorm batch statistics of

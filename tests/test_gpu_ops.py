@@ -296,3 +296,55 @@ def test_linear_wgrad_with_bias(ntok, Ci, Co):
     assert float((db.double() - want_b).norm() / want_b.norm()) < 1e-5
     dw2, db2 = ops.linear_wgrad(x, dy, Ci, Co)
     assert torch.equal(dw, dw2) and torch.equal(db, db2)          # fixed summation order
+
+
+@pytest.mark.parametrize("shape", [(2, 37, 18, 48, 48), (1, 70, 50, 144, 48), (3, 33, 16, 48, 144), (1, 32, 16, 40, 40),
+                                   (2, 5, 3, 8, 48), (1, 96, 64, 48, 48), (5, 64, 64, 96, 48), (40, 64, 64, 48, 48),
+                                   (3, 100, 40, 48, 40), (1, 2, 3, 48, 48)])
+def test_conv_48_channel_blocks_bf16(shape):
+    """48-channel output blocks (bf16, 3x3), among them the persistent whole-pixel kernel that takes the layers with
+    33..48 input and up to 48 output channels: ragged images, partial channel counts, one and many tiles per
+    workgroup; batch statistics, folded scale/shift + ReLU, split outputs, and the fused pool / 1x1 head epilogues."""
+    from unet_amd import ops
+    dt = torch.bfloat16
+    B, H, W, Ci, Co = shape
+    x = rnd((B, Ci, H, W), 41, dt)
+    w = rnd((Co, Ci, 3, 3), 42, dt, (2.0 / (Ci * 9)) ** 0.5)
+    ref = F.conv2d(x, w, None, padding=1)
+    xd = nhwc(x, dt)
+    pw = ops.PackedConv(w.cuda(), dt)
+    assert pw.bn == 48
+    y, stats = ops.conv_fwd(xd, pw, want_stats=True)
+    assert rel(nchw(y), ref) < TOL[dt]
+    s = stats.double().sum(0).cpu()
+    assert rel(s[0], ref.double().sum((0, 2, 3))) < 2e-3 or ref.double().sum((0, 2, 3)).abs().max() < 1e-2
+    assert rel(s[1], (ref.double() ** 2).sum((0, 2, 3))) < 1e-2
+    y_again, stats_again = ops.conv_fwd(xd, pw, want_stats=True)
+    assert torch.equal(y, y_again) and torch.equal(stats, stats_again)
+    # input that is a channel slice of a wider buffer, output into a channel slice
+    wide_in = torch.randn((B, H, W, Ci + 16), device="cuda").to(dt)
+    wide_in[..., 8:8 + Ci] = xd
+    wide_out = torch.zeros((B, H, W, Co + 8), dtype=dt, device="cuda")
+    y3, _ = ops.conv_fwd(wide_in[..., 8:8 + Ci], pw, out=wide_out[..., 8:])
+    assert torch.equal(y3, y) and float(wide_out[..., :8].abs().max()) == 0.0
+    sc, sh = (torch.rand(Co) + 0.5), (torch.randn(Co) * 0.3)
+    ya, _ = ops.conv_fwd(xd, pw, scale=sc.cuda(), shift=sh.cuda(), act=1)
+    assert rel(nchw(ya), F.relu(ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))) < TOL[dt]
+    if Co == 144:
+        for split in (48, 96):
+            (p, r), _ = ops.conv_fwd(xd, pw, split=split)
+            assert torch.equal(torch.cat((p, r), -1), y)
+    y2, pooled, _ = ops.conv_fwd(xd, pw, scale=sc.cuda(), shift=sh.cuda(), act=1, pool=True)
+    assert torch.equal(y2, ya) and torch.equal(pooled, ops.maxpool2x2(ya))
+    if Co <= 48:
+        hw, hb = torch.randn(2, Co, 1, 1).cuda() * 0.2, torch.randn(2).cuda()
+        o, p, head = ops.conv_fwd(xd, pw, scale=sc.cuda(), shift=sh.cuda(), act=1, head=(hw, hb), write_out=False)
+        assert o is None and p is None
+        assert rel(head.cpu(), ops.head1x1_fwd(ya, hw, hb).cpu()) < 1e-5
+    # data gradient through the same kernel (transposed, flipped pack)
+    gy = rnd((B, Co, H, W), 43, dt)
+    xr, wr = x.clone().requires_grad_(True), w.clone()
+    F.conv2d(xr, wr, None, padding=1).backward(gy)
+    pwt = ops.PackedConv(w.cuda(), dt, transpose=True)
+    dx, _ = ops.conv_fwd(nhwc(gy, dt), pwt)
+    assert rel(nchw(dx), xr.grad) < TOL[dt]

@@ -22,6 +22,16 @@ def timeit(fn, n=5):
     return e0.elapsed_time(e1) / n
 
 
+# what a plain library copy / read reaches on this card at the same sizes (the practical ceiling)
+for mb in (100, 403, 1600):
+    n = mb * 1000 * 1000 // 2
+    src = torch.randn(n, device="cuda").to(dt)
+    dst = torch.empty_like(src)
+    t_c = timeit(lambda: dst.copy_(src))
+    t_r = timeit(lambda: torch.sum(src.view(torch.int16), dtype=torch.int32))
+    print(f"ceiling {mb:5d} MB: torch copy {2 * mb / 1e3 / t_c:5.2f} TB/s, torch read-sum {mb / 1e3 / t_r:5.2f} TB/s", flush=True)
+    del src, dst
+
 tot = {}
 for hw, C in levels:
     S = B * hw * hw * C * 2 / 1e9     # GB of one activation tensor

@@ -653,6 +653,492 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   conv_igemm_body<T, NT, KS, false, FUSE>(a);
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3x3 conv, up to 48 input and 48 output channels (bf16): the full-resolution layers of the UNet.
+// Measured on those shapes, the generic kernel is bound by the CU's vector-memory address path, not
+// by MFMA or HBM: an LDS-DMA piece (1 KiB per wave instruction) whose lanes gather 64-byte runs - one
+// 32-channel chunk of 16 pixels that are 96 bytes apart - takes ~100 cycles of that path, a piece
+// that reads 1 KiB of consecutive memory ~35.  So here a pixel is staged whole (96 bytes, all 48
+// channels): a halo row is one run of 18 x 96 consecutive bytes, the LDS image is a byte-for-byte copy
+// of those runs (96-byte pixel pitch: fragment reads of 16 neighbouring pixels are bank-conflict free
+// as they stand), and a piece is a linear 1 KiB slice of it.
+//
+// One persistent workgroup of eight waves per CU walks a contiguous range of 16-column x 32-row
+// tiles.  All weights live in LDS for the whole launch; the 18x34 halo of the next tile lands in the
+// second halo buffer while the current one is multiplied (one barrier per tile, 168 MFMAs per wave
+// between barriers).  K = 9 taps x 48 channels is cut into 14 steps of 32: nine steps take channels
+// 0..31 of one tap, five take channels 32..47 of TWO taps (lanes with k < 16 read one tap's pixel,
+// lanes with k >= 16 the other's: a per-lane address, nothing else) - no multiply is spent on padding
+// except half of the last step.  The MFMA operands are swapped - weights are the A operand, pixels
+// the B operand - so a lane ends up with 12 output channels of one pixel: the weight rows of the
+// three 16-channel MFMA tiles are interleaved on their way into LDS (tiles 0 and 1, row 4q+r: channel
+// 8q+4t+r; tile 2: channel 32+4q+r), a lane's values are 8 + 4 consecutive channels and leave as one
+// 16-byte and one 8-byte store straight from registers: no staging tile, no extra barriers.  Wave w
+// owns tile rows 4w..4w+3; in the nine full steps a pixel fragment read for halo row r and column
+// shift kx serves the three kernel rows (output rows r, r-1, r-2).
+// The address path is shared by the CU: eight waves issuing DMA at the same moment all wait for each
+// other while the matrix pipe idles.  So the next tile's DMA and the previous tile's stores are cut
+// into four parts, one per block of MFMAs, and the two waves that share a SIMD (w and w+4) issue
+// theirs at different points of the block: one of them is always multiplying.
+constexpr int P48_PIXB = 96;                         // LDS bytes per staged pixel (48 channels)
+constexpr int P48_ROWB = 18 * P48_PIXB;              // one halo row
+constexpr int P48_HBYTES = 34 * P48_ROWB;            // 58752
+constexpr int P48_HINSTR = (P48_HBYTES + 1023) / 1024;   // 58 pieces, the last one partial
+constexpr int P48_HBUF = (P48_HBYTES + 255) / 256 * 256;
+constexpr int P48_KSTEPS = 14;
+constexpr int P48_WINSTR = P48_KSTEPS * 3;           // 48 rows x 64 B per step
+constexpr int P48_WBUF = P48_WINSTR * 1024;
+
+template <int CTRL> __device__ __forceinline__ float p48_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// sum over the 16 lanes that share lane>>4 (pairs, quads, half mirror, row mirror)
+__device__ __forceinline__ float p48_row_sum(float v) {
+  v += p48_dpp<0xB1>(v);
+  v += p48_dpp<0x4E>(v);
+  v += p48_dpp<0x141>(v);
+  v += p48_dpp<0x140>(v);
+  return v;
+}
+__device__ __forceinline__ uint32_t p48_pack2(float lo, float hi) {
+  const bf16 l = (bf16)lo, h = (bf16)hi;
+  return (uint32_t)__builtin_bit_cast(unsigned short, l) | ((uint32_t)__builtin_bit_cast(unsigned short, h) << 16);
+}
+
+struct P48Item {
+  int b, ty, tx;
+};
+
+template <bool FUSE>
+__global__ __launch_bounds__(512) void conv3x3_p48_kernel(ConvArgs a) {
+  using T = bf16;
+  using frag = bf16x8;
+  // Separate LDS objects (not one array indexed by the tile's parity): the compiler then knows that
+  // the DMA filling one halo buffer cannot alias the fragment reads of the other and leaves it in
+  // flight during the multiply.  Together they are exactly the CU's 160 KiB.
+  __shared__ __attribute__((aligned(256))) char halo0[P48_HBUF];
+  __shared__ __attribute__((aligned(256))) char halo1[P48_HBUF];
+  __shared__ __attribute__((aligned(256))) char wlds[P48_WBUF];
+  __shared__ float red[8][2][48];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, q = lane >> 4;
+  const bool early = wave < 4;                 // waves w and w+4 share a SIMD: they take turns at the address path
+  const T* in = reinterpret_cast<const T*>(a.in);
+  const T* wp = reinterpret_cast<const T*>(a.w);
+  const T* zero = reinterpret_cast<const T*>(conv_zero_page);
+
+  // this workgroup's contiguous range of tiles; each XCD (workgroups are dealt to them round-robin)
+  // takes a contiguous eighth, so neighbouring halos share an L2
+  const int tiles_y32 = (a.H + 31) >> 5;
+  const int nitems = a.B * tiles_y32 * a.tiles_x;
+  const int nwg = gridDim.x;
+  const int pos = (blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3);
+  const int per = (nitems + nwg - 1) / nwg;
+  const int first = pos * per;
+  int mine = nitems - first;
+  if (mine > per) mine = per;
+  if (mine <= 0) return;
+  auto advance = [&](P48Item& it) __attribute__((always_inline)) {
+    if (++it.tx == a.tiles_x) {
+      it.tx = 0;
+      if (++it.ty == tiles_y32) {
+        it.ty = 0;
+        ++it.b;
+      }
+    }
+  };
+  P48Item nxt;                               // the tile whose DMA goes out next
+  nxt.tx = first % a.tiles_x;
+  nxt.ty = (first / a.tiles_x) % tiles_y32;
+  nxt.b = first / a.tiles_x / tiles_y32;
+  P48Item cur = nxt;                         // the tile being multiplied
+
+  // ---- weights, once: 14 K-steps x 48 rows x 64 B.  Piece j: step j/3, MFMA tile j%3.  Steps 0..8 are
+  // channels 0..31 of tap s; step 9+p holds channels 32..47 of tap 2p (k < 16) and of tap 2p+1 (k >= 16).
+  {
+    const int m = lane >> 2, slot = (lane & 3) ^ swz(m);
+    const long chunk1 = 9L * 48 * 32;
+#pragma unroll
+    for (int k = 0; k < (P48_WINSTR + 7) / 8; ++k) {
+      const int j = wave + 8 * k;
+      if (j < P48_WINSTR) {
+        const int st = j / 3, t = j - 3 * st;
+        const int chan = t < 2 ? 8 * (m >> 2) + 4 * t + (m & 3) : 32 + m;
+        const T* src;
+        if (st < 9) {
+          src = wp + ((long)st * 48 + chan) * 32 + slot * 8;
+        } else {
+          const int tap = 2 * (st - 9) + (slot >> 1);
+          src = (tap < 9 && a.nchunks > 1) ? wp + chunk1 + ((long)tap * 48 + chan) * 32 + (slot & 1) * 8 : zero;
+        }
+        glds16(src, wlds + j * 1024);
+      }
+    }
+  }
+
+  // ---- halo DMA source table: piece i = wave + 8k is bytes [1024 i, 1024 i + 1024) of the halo image
+  constexpr int HPW = (P48_HINSTR + 7) / 8;
+  int hp_off[HPW], hp_yx[HPW];
+#pragma unroll
+  for (int k = 0; k < HPW; ++k) {
+    const int o = (wave + 8 * k) * 1024 + lane * 16;
+    const int r = o / P48_ROWB, rem = o - r * P48_ROWB;
+    const int px = rem / P48_PIXB, cb = rem - px * P48_PIXB;
+    hp_off[k] = (r * a.W + px) * a.ldin + (cb >> 1);
+    // bit 31: nothing to write (past the image of the halo); a row no image has: read zeros
+    hp_yx[k] = o >= P48_HBYTES ? (int)0x80000000 : ((cb >> 1) < a.Ci ? ((r << 16) | px) : (0x4000 << 16));
+  }
+  const T* hbase = nullptr;
+  int iy0 = 0, ix0 = 0;
+  auto issue_begin = [&]() __attribute__((always_inline)) {
+    iy0 = nxt.ty * 32 - 1;
+    ix0 = nxt.tx * 16 - 1;
+    hbase = in + (((long)nxt.b * a.H + iy0) * a.W + ix0) * a.ldin;
+    advance(nxt);
+  };
+  auto issue_part = [&](auto parc, auto gc) __attribute__((always_inline)) {       // pieces 2G, 2G+1 of this wave
+    constexpr int P = decltype(parc)::value, G = decltype(gc)::value;
+    char* hdst = P ? halo1 : halo0;
+#pragma unroll
+    for (int k = 2 * G; k < 2 * G + 2 && k < HPW; ++k) {
+      const int i = wave + 8 * k;
+      if (i < P48_HINSTR && hp_yx[k] >= 0) {
+        const int hy = hp_yx[k] >> 16, hx = hp_yx[k] & 0xffff;
+        const bool ok = (unsigned)(iy0 + hy) < (unsigned)a.H && (unsigned)(ix0 + hx) < (unsigned)a.W;
+        glds16(ok ? hbase + hp_off[k] : zero, hdst + i * 1024);
+      }
+    }
+  };
+
+  // ---- fragment addresses: a lane register plus immediates
+  const int p_lane = (4 * wave * 18 + l15) * P48_PIXB + 16 * q;       // full steps: + ((r*18 + kx) * 96)
+  int t_lane[5];                                                       // paired steps: + (i*18*96)
+#pragma unroll
+  for (int p = 0; p < 5; ++p) {
+    int tap = 2 * p + (q >> 1);
+    if (tap > 8) tap = 8;                  // (its weights are zeros; any finite pixel will do)
+    t_lane[p] = (4 * wave * 18 + l15 + (tap / 3) * 18 + tap % 3) * P48_PIXB + 64 + 16 * (q & 1);
+  }
+  const int w_lane = l15 * ROWB + ((q ^ swz(l15)) * 16);
+
+  f32x4 acc[4][3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // halo rows [R0, R1) of kernel column kx (steps kx, 3+kx, 6+kx): 18 of its 36 MFMAs for (0,3) and (3,6)
+  frag wf[3][3];
+  auto load_wcol = [&](auto kxc) __attribute__((always_inline)) {
+    constexpr int kx = decltype(kxc)::value;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        wf[ky][t] = *reinterpret_cast<const frag*>(wlds + w_lane + (((ky * 3 + kx) * 48 + t * 16) * ROWB));
+  };
+  auto col_rows = [&](auto parc, auto kxc, auto r0c, auto r1c) __attribute__((always_inline)) {
+    constexpr int P = decltype(parc)::value, kx = decltype(kxc)::value, R0 = decltype(r0c)::value, R1 = decltype(r1c)::value;
+    const char* halo = P ? halo1 : halo0;
+    frag pf[R1 - R0];
+#pragma unroll
+    for (int r = R0; r < R1; ++r) pf[r - R0] = *reinterpret_cast<const frag*>(halo + p_lane + (r * 18 + kx) * P48_PIXB);
+#pragma unroll
+    for (int r = R0; r < R1; ++r) {
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int i = r - ky;
+        if (i >= 0 && i < 4) {
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ky][t], pf[r - R0], acc[i][t], 0, 0, 0);
+        }
+      }
+    }
+  };
+  // paired steps [P0, P1): channels 32..47 of taps 2p and 2p+1
+  auto tails = [&](auto parc, auto p0c, auto p1c) __attribute__((always_inline)) {
+    constexpr int P = decltype(parc)::value, P0 = decltype(p0c)::value, P1 = decltype(p1c)::value;
+    const char* halo = P ? halo1 : halo0;
+#pragma unroll
+    for (int p = P0; p < P1; ++p) {
+      frag wt[3], pf[4];
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        wt[t] = *reinterpret_cast<const frag*>(wlds + w_lane + (((9 + p) * 48 + t * 16) * ROWB));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pf[i] = *reinterpret_cast<const frag*>(halo + t_lane[p] + i * 18 * P48_PIXB);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[t], pf[i], acc[i][t], 0, 0, 0);
+    }
+  };
+
+  // Per-channel epilogue constants of the lane's 12 channels.  Slot j = 4t+r: tiles 0/1 -> channel 8q+j,
+  // tile 2 -> 32+4q+r.
+  auto chan_of = [&](int j) __attribute__((always_inline)) { return j < 8 ? 8 * q + j : 32 + 4 * q + (j - 8); };
+  const bool affine = a.ep_scale != nullptr || a.ep_shift != nullptr;
+  float esc[12], esh[12], hw0[FUSE ? 12 : 1];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) {
+    const int c = chan_of(j);
+    const int cc = c < a.Co ? c : 0;
+    const float sc = a.ep_scale != nullptr ? a.ep_scale[cc] : 1.f;
+    const float sh = a.ep_shift != nullptr ? a.ep_shift[cc] : 0.f;
+    esc[j] = c < a.Co ? sc : 1.f;
+    esh[j] = c < a.Co ? sh : 0.f;
+    if constexpr (FUSE) {
+      const float h = a.head_out != nullptr ? a.head_w[cc] : 0.f;
+      hw0[j] = c < a.Co ? h : 0.f;
+    }
+  }
+
+  // ---- the finished tile: results packed to bf16 in registers (pk), stored during the next tile
+  uint32_t pk[4][6];
+  P48Item done = cur;
+  bool pending = false;
+  float ssum[12], ssq[12];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) ssum[j] = ssq[j] = 0.f;
+  auto finish_item = [&]() __attribute__((always_inline)) {
+    done = cur;
+    const int gx = cur.tx * 16 + l15;
+    const bool colok = gx < a.W;
+    const int gy0 = cur.ty * 32 + 4 * wave;
+    if (a.stats != nullptr) {
+      // batch statistics: per-lane running sums over all tiles of the workgroup (reduced across lanes
+      // and waves once, at the end of the kernel)
+      const bool full = cur.ty * 32 + 32 <= a.H && cur.tx * 16 + 16 <= a.W;
+      if (full) {
+#pragma unroll
+        for (int j = 0; j < 12; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float v = acc[i][j >> 2][j & 3];
+            ssum[j] += v;
+            ssq[j] += v * v;
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float m = (colok && gy0 + i < a.H) ? 1.f : 0.f;
+#pragma unroll
+          for (int j = 0; j < 12; ++j) {
+            const float v = acc[i][j >> 2][j & 3] * m;
+            ssum[j] += v;
+            ssq[j] += v * v;
+          }
+        }
+      }
+    }
+    // folded BatchNorm / bias and the activation; from here on the values as they are stored
+    if (affine) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][t][r] = acc[i][t][r] * esc[4 * t + r] + esh[4 * t + r];
+    }
+    if (a.act == 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][t][r] = fmaxf(acc[i][t][r], 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        pk[i][2 * t] = p48_pack2(acc[i][t][0], acc[i][t][1]);
+        pk[i][2 * t + 1] = p48_pack2(acc[i][t][2], acc[i][t][3]);
+      }
+    if constexpr (FUSE) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][t][r] = to_f32(from_f32<T>(acc[i][t][r]));
+      if (a.pooled != nullptr) {
+        T* pl = reinterpret_cast<T*>(a.pooled);
+        const int PH = a.H >> 1, PW = a.W >> 1;
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+          const int py = (gy0 + 2 * i2) >> 1, px = gx >> 1;
+          uint32_t o[6];
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            float m[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              m[r] = fmaxf(acc[2 * i2][t][r], acc[2 * i2 + 1][t][r]);
+              m[r] = fmaxf(m[r], p48_dpp<0xB1>(m[r]));      // the neighbouring column
+            }
+            o[2 * t] = p48_pack2(m[0], m[1]);
+            o[2 * t + 1] = p48_pack2(m[2], m[3]);
+          }
+          if ((l15 & 1) == 0 && py < PH && px < PW) {
+            T* dst = pl + (((long)cur.b * PH + py) * PW + px) * a.Co;
+            if (8 * q < a.Co) *reinterpret_cast<u32x4*>(dst + 8 * q) = u32x4{o[0], o[1], o[2], o[3]};
+            if (32 + 4 * q < a.Co) *reinterpret_cast<uint2*>(dst + 32 + 4 * q) = uint2{o[4], o[5]};
+          }
+        }
+      }
+      if (a.head_out != nullptr) {
+        // trailing 1x1 conv: the lane's partial dot product over its 12 channels, then the four
+        // lanes (q = 0..3) of a pixel are added.  Output 0 uses the weights held in registers.
+        for (int o = 0; o < a.head_co; ++o) {
+          float hw[12];
+#pragma unroll
+          for (int j = 0; j < 12; ++j) {
+            const int c = chan_of(j);
+            hw[j] = o == 0 ? hw0[j] : (c < a.Co ? a.head_w[(long)o * a.Co + c] : 0.f);
+          }
+          const float hb = a.head_b ? a.head_b[o] : 0.f;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float sdot = 0.f;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) sdot += acc[i][t][r] * hw[4 * t + r];
+            sdot += __shfl_xor(sdot, 16, 64);
+            sdot += __shfl_xor(sdot, 32, 64);
+            if (q == 0 && colok && gy0 + i < a.H)
+              a.head_out[(((long)cur.b * a.head_co + o) * a.H + gy0 + i) * a.W + gx] = sdot + hb;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    pending = true;
+  };
+  // row G of the finished tile's result
+  auto store_part = [&](auto gc) __attribute__((always_inline)) {
+    constexpr int G = decltype(gc)::value;
+    if (a.out == nullptr) return;
+    const int gy = done.ty * 32 + 4 * wave + G;
+    const int gx = done.tx * 16 + l15;
+    if (gy < a.H && gx < a.W) {
+      T* dst = reinterpret_cast<T*>(a.out) + (((long)done.b * a.H + gy) * a.W + gx) * a.ldout;
+      if (8 * q < a.Co) *reinterpret_cast<u32x4*>(dst + 8 * q) = u32x4{pk[G][0], pk[G][1], pk[G][2], pk[G][3]};
+      if (32 + 4 * q < a.Co) *reinterpret_cast<uint2*>(dst + 32 + 4 * q) = uint2{pk[G][4], pk[G][5]};
+    }
+  };
+
+#ifdef P48_PROF
+  long prof[6] = {0, 0, 0, 0, 0, 0};
+  const long tstart = __builtin_readcyclecounter();
+#endif
+  issue_begin();
+  issue_part(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+  issue_part(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+  issue_part(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+  issue_part(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
+  auto tile_step = [&](auto parc, int s) __attribute__((always_inline)) {
+    constexpr int P = decltype(parc)::value;
+    using PN = std::integral_constant<int, P ^ 1>;
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    using I5 = std::integral_constant<int, 5>;
+    using I6 = std::integral_constant<int, 6>;
+    // Tile s has landed (this wave's pieces; after the barrier everyone's), every wave is done with
+    // the halo buffer tile s+1 goes into, and the statistics partials of the finished tile are visible.
+    // (The wait is the builtin, not inline asm: the compiler then knows that no DMA is in flight
+    // here and does not put a vmcnt(0) of its own in front of the first fragment read.)
+#ifdef P48_PROF
+#define STAMP(k) { const long t_ = __builtin_readcyclecounter(); prof[k] += t_ - tl; tl = t_; }
+    long tl = __builtin_readcyclecounter();
+#else
+#define STAMP(k)
+#endif
+    __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
+    STAMP(0)
+    asm volatile("s_barrier" ::: "memory");
+    STAMP(1)
+    const bool more = s + 1 < mine;
+    const bool st = pending;
+    pending = false;
+    if (more) issue_begin();
+    auto side = [&](auto gc) __attribute__((always_inline)) {
+      STAMP(4)
+      if (more) issue_part(PN{}, gc);
+      STAMP(2)
+      if (st) store_part(gc);
+      STAMP(3)
+    };
+    load_wcol(I0{});
+    if (early) side(I0{});
+    col_rows(parc, I0{}, I0{}, I3{});
+    if (!early) side(I0{});
+    col_rows(parc, I0{}, I3{}, I6{});
+    load_wcol(I1{});
+    if (early) side(I1{});
+    col_rows(parc, I1{}, I0{}, I3{});
+    if (!early) side(I1{});
+    col_rows(parc, I1{}, I3{}, I6{});
+    load_wcol(I2{});
+    if (early) side(I2{});
+    col_rows(parc, I2{}, I0{}, I3{});
+    if (!early) side(I2{});
+    col_rows(parc, I2{}, I3{}, I6{});
+    if (early) side(I3{});
+    tails(parc, I0{}, I2{});
+    if (!early) side(I3{});
+    tails(parc, I2{}, I5{});
+    STAMP(4)
+    finish_item();
+    advance(cur);
+    STAMP(5)
+  };
+#pragma unroll 1
+  for (int s = 0; s < mine; s += 2) {
+    tile_step(std::integral_constant<int, 0>{}, s);
+    if (s + 1 < mine) tile_step(std::integral_constant<int, 1>{}, s + 1);
+  }
+  store_part(std::integral_constant<int, 0>{});
+  store_part(std::integral_constant<int, 1>{});
+  store_part(std::integral_constant<int, 2>{});
+  store_part(std::integral_constant<int, 3>{});
+  if (a.stats != nullptr) {
+    // one row of partial sums per workgroup: lanes of a pixel row by DPP, the eight waves through LDS
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      const float sv = p48_row_sum(ssum[j]), qv = p48_row_sum(ssq[j]);
+      if (l15 == 0) {
+        red[wave][0][chan_of(j)] = sv;
+        red[wave][1][chan_of(j)] = qv;
+      }
+    }
+    __syncthreads();
+    if (tid < 96) {
+      const int which = tid / 48, c = tid % 48;
+      if (c < a.Co) {
+        float v = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) v += red[w8][which][c];
+        a.stats[(long)pos * 2 * a.Co + (long)which * a.Co + c] = v;
+      }
+    }
+  }
+#ifdef P48_PROF
+  if (blockIdx.x == 8 && lane == 0 && (wave == 0 || wave == 5))
+    printf("p48 wave %d tiles %d: vmwait %ld barrier %ld issue %ld stores %ld mfma %ld finish %ld total %ld (cycles per tile)\n",
+           wave, mine, prof[0] / mine, prof[1] / mine, prof[2] / mine, prof[3] / mine, prof[4] / mine, prof[5] / mine,
+           (long)(__builtin_readcyclecounter() - tstart) / mine);
+#endif
+}
+
 // ---- weight packing: [Co][Ci][KS][KS] f32 -> [nblk][nchunk][tap][BN][KC] T
 template <typename T>
 __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ dst, int Co, int Ci,
@@ -717,6 +1203,24 @@ __global__ void pack_weights_batched_kernel(const long* __restrict__ jobs, const
   dst[idx] = from_f32<T>(v);
 }
 
+// up to 48 -> 48 channels, bf16, 3x3 (the full-resolution layers): the persistent whole-pixel kernel (it has
+// no residual, GELU or split-output epilogue)
+inline bool use_p48(const ConvArgs& a, int bn) {
+  static const bool off = getenv("UNETK_NO_P48") != nullptr;
+  return bn == 48 && a.Co <= 48 && a.Ci > 32 && a.Ci <= 48 && !off && a.resid == nullptr && a.out2 == nullptr &&
+         a.act <= 1 && (int64_t)a.W * a.ldin * 36 < (1LL << 31);
+}
+inline int p48_items(const ConvArgs& a) { return a.B * cdiv(a.H, 32) * cdiv(a.W, 16); }
+inline int p48_workgroups(const ConvArgs& a) {
+  const int n = p48_items(a);
+  return n < 256 ? 8 * cdiv(n, 8) : 256;
+}
+// workgroups that have tiles = rows of batch statistics written
+inline int p48_stats_rows(const ConvArgs& a) {
+  const int n = p48_items(a), per = cdiv(n, p48_workgroups(a));
+  return cdiv(n, per);
+}
+
 template <typename T, int KS>
 int launch_conv(ConvArgs a, int bn, hipStream_t stream) {
   const long npix = (long)a.B * a.H * a.W;
@@ -724,6 +1228,17 @@ int launch_conv(ConvArgs a, int bn, hipStream_t stream) {
   a.tiles_per_xcd = cdiv(a.ntiles, 8);
   a.nby = cdiv(a.Co, bn);
   dim3 grid((unsigned)(8 * a.tiles_per_xcd * a.nby));
+  if constexpr (KS == 3 && sizeof(T) == 2) {
+    if (use_p48(a, bn)) {
+      const int nwg = p48_workgroups(a);
+      if (a.pooled != nullptr || a.head_out != nullptr)
+        hipLaunchKernelGGL((conv3x3_p48_kernel<true>), dim3(nwg), dim3(512), 0, stream, a);
+      else
+        hipLaunchKernelGGL((conv3x3_p48_kernel<false>), dim3(nwg), dim3(512), 0, stream, a);
+      UNETK_CHECK_LAUNCH();
+      return UNETK_OK;
+    }
+  }
   if constexpr (KS == 3) {
     if (a.pooled != nullptr || a.head_out != nullptr) {      // inference-time fused epilogue
       switch (bn) {
@@ -818,6 +1333,15 @@ int unetk_conv_pack_weights(const int64_t* jobs, const int* blocks, int nblocks,
 int unetk_conv_num_tiles(int B, int H, int W, int ks) {
   if (ks == 3) return B * cdiv(H, 16) * cdiv(W, 16);
   return cdiv((long)B * H * W, 256);
+}
+
+int unetk_conv_stats_rows(int B, int H, int W, int Ci, int Co, int ks, int bn, int dtype, int ldin, int act) {
+  if (ks == 3 && dtype == UNETK_BF16) {
+    ConvArgs a = {};
+    a.B = B; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.ldin = ldin; a.act = act;
+    if (use_p48(a, bn)) return p48_stats_rows(a);
+  }
+  return unetk_conv_num_tiles(B, H, W, ks);
 }
 
 int unetk_conv_fwd_fused(const void* in, int ldin, const void* wpacked, void* out, int ldout, void* out2,

@@ -197,7 +197,9 @@ def conv_fwd(x: torch.Tensor, pw: PackedConv, Ci: Optional[int] = None, Co: Opti
     ldout = out.stride(2)          # `out` may be a channel slice of a wider (concat) buffer
     stats = None
     if want_stats:
-        nt = _lib.load().unetk_conv_num_tiles(B, H, W, pw.ks)
+        if resid is not None:
+            raise ValueError("conv_fwd: batch statistics and a residual are exclusive")
+        nt = _lib.load().unetk_conv_stats_rows(B, H, W, Ci, Co, pw.ks, pw.bn, dtype_code(dt), ldin, act)
         stats = torch.empty((nt, 2, Co), dtype=torch.float32, device=x.device)
     call("unetk_conv_fwd", ptr(x), ldin, ptr(pw.data), ptr(out), ldout, B, H, W, Ci, Co, pw.ks, pw.bn,
          dtype_code(dt), ptr(stats), ptr(scale), ptr(shift), act, ptr(resid),
