@@ -76,6 +76,17 @@ int unetk_conv_fwd_split(const void* in, int ldin, const void* wpacked, void* ou
  * max-pool of the stored output (training.py:464-473, dense [B][H/2][W/2][Co]); head_out (nullable,
  * NCHW fp32 [B][head_co][H][W]) receives the network's final 1x1 conv with bias applied to the
  * stored output (training.py:482,520; needs Co <= bn).  out may be NULL when only head_out is wanted. */
+/* unetk_conv_fwd (3x3) whose input is the channel concatenation [in | in2] of two NHWC tensors, read in place:
+ * the decoder's torch.cat((dec, enc), dim=1) before its first conv (training.py:504-517) is never stored.
+ * Ci1 channels come from `in` (a multiple of 32 for bf16, 16 for f32), Ci - Ci1 from `in2`; the packed weights
+ * are those of the concatenated layer. */
+int unetk_conv_fwd_cat(const void* in, int ldin, int Ci1, const void* in2, int ldin2, const void* wpacked, void* out,
+                       int ldout, int B, int H, int W, int Ci, int Co, int bn, int dtype, float* stats,
+                       const float* ep_scale, const float* ep_shift, int act, unetk_stream_t stream);
+/* ... and its weight gradient (workspace as unetk_conv_wgrad_workspace_bytes for the whole Ci). */
+int unetk_conv_wgrad_cat(const void* in, int ldin, int Ci1, const void* in2, int ldin2, const void* dy, int lddy,
+                         float* dw, int B, int H, int W, int Ci, int Co, int dtype, void* workspace,
+                         int64_t workspace_bytes, int accumulate, unetk_stream_t stream);
 int unetk_conv_fwd_fused(const void* in, int ldin, const void* wpacked, void* out, int ldout, void* out2,
                          int ldout2, int split, void* pooled, const float* head_w, const float* head_b,
                          float* head_out, int head_co, int B, int H, int W, int Ci, int Co, int ks, int bn,

@@ -326,17 +326,20 @@ def test_conv_48_channel_blocks_bf16(shape):
     wide_in[..., 8:8 + Ci] = xd
     wide_out = torch.zeros((B, H, W, Co + 8), dtype=dt, device="cuda")
     y3, _ = ops.conv_fwd(wide_in[..., 8:8 + Ci], pw, out=wide_out[..., 8:])
-    assert torch.equal(y3, y) and float(wide_out[..., :8].abs().max()) == 0.0
+    y_plain, _ = ops.conv_fwd(xd, pw)        # (with and without statistics different kernels may run: same sums, other order)
+    assert rel(nchw(y_plain), ref) < TOL[dt] and rel(y_plain.float().cpu(), y.float().cpu()) < 2e-3
+    assert torch.equal(y3, y_plain) and float(wide_out[..., :8].abs().max()) == 0.0
     sc, sh = (torch.rand(Co) + 0.5), (torch.randn(Co) * 0.3)
     ya, _ = ops.conv_fwd(xd, pw, scale=sc.cuda(), shift=sh.cuda(), act=1)
     assert rel(nchw(ya), F.relu(ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))) < TOL[dt]
     if Co == 144:
         for split in (48, 96):
             (p, r), _ = ops.conv_fwd(xd, pw, split=split)
-            assert torch.equal(torch.cat((p, r), -1), y)
+            assert torch.equal(torch.cat((p, r), -1), y_plain)
     y2, pooled, _ = ops.conv_fwd(xd, pw, scale=sc.cuda(), shift=sh.cuda(), act=1, pool=True)
-    assert torch.equal(y2, ya) and torch.equal(pooled, ops.maxpool2x2(ya))
+    assert rel(y2.float().cpu(), ya.float().cpu()) < 2e-3 and torch.equal(pooled, ops.maxpool2x2(y2))
     if Co <= 48:
+        assert torch.equal(y2, ya)
         hw, hb = torch.randn(2, Co, 1, 1).cuda() * 0.2, torch.randn(2).cuda()
         o, p, head = ops.conv_fwd(xd, pw, scale=sc.cuda(), shift=sh.cuda(), act=1, head=(hw, hb), write_out=False)
         assert o is None and p is None
@@ -348,3 +351,35 @@ def test_conv_48_channel_blocks_bf16(shape):
     pwt = ops.PackedConv(w.cuda(), dt, transpose=True)
     dx, _ = ops.conv_fwd(nhwc(gy, dt), pwt)
     assert rel(nchw(dx), xr.grad) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 20, 33, 32, 16, 64), (1, 37, 18, 96, 48, 48), (2, 16, 16, 64, 8, 96),
+                                   (1, 40, 24, 192, 96, 96), (1, 9, 70, 32, 40, 32)])
+def test_conv_of_a_concatenation_read_in_place(dt, shape):
+    """conv3x3(cat([x1, x2])) and its weight gradient with the two tensors read as two operands (wide buffers'
+    channel slices included): the same bits as on the stored concatenation."""
+    from unet_amd import ops
+    B, H, W, C1, C2, Co = shape
+    x1 = nhwc(rnd((B, C1, H, W), 51, dt), dt)
+    wide = torch.randn((B, H, W, C2 + 24), device="cuda").to(dt)
+    x2 = wide[..., 8:8 + C2]
+    cat = torch.cat((x1, x2), -1).contiguous()
+    w = rnd((Co, C1 + C2, 3, 3), 52, dt, (2.0 / ((C1 + C2) * 9)) ** 0.5)
+    pw = ops.PackedConv(w.cuda(), dt)
+    want, want_stats = ops.conv_fwd(cat, pw, want_stats=True)
+    got, got_stats = ops.conv_fwd_cat(x1, x2, pw, want_stats=True)
+    assert torch.equal(got, want) and torch.equal(got_stats, want_stats)
+    ref = F.conv2d(nchw(cat), w, None, padding=1)
+    assert rel(nchw(got), ref) < TOL[dt]
+    sc, sh = (torch.rand(Co) + 0.5).cuda(), (torch.randn(Co) * 0.3).cuda()
+    assert torch.equal(ops.conv_fwd_cat(x1, x2, pw, scale=sc, shift=sh, act=1)[0],
+                       ops.conv_fwd(cat, pw, scale=sc, shift=sh, act=1)[0])
+    dy = nhwc(rnd((B, Co, H, W), 53, dt), dt)
+    assert torch.equal(ops.conv_wgrad((x1, x2), dy, C1 + C2, Co, 3), ops.conv_wgrad(cat, dy, C1 + C2, Co, 3))
+    with pytest.raises(ValueError):
+        ops.conv_fwd_cat(x1[..., :C1 - 8], torch.cat((x1[..., C1 - 8:], x2), -1).contiguous(), pw)   # not whole chunks
+    up = ops.upsample(x1[:, :H // 2 or 1, :W // 2 or 1].contiguous(), H, W)
+    both = torch.zeros((B, H, W, C1 + 8), dtype=dt, device="cuda")
+    ops.upsample_into(x1[:, :H // 2 or 1, :W // 2 or 1].contiguous(), both)
+    assert torch.equal(up, both[..., :C1])

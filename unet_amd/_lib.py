@@ -41,6 +41,8 @@ _SIGNATURES = {
     "unetk_conv_fwd_fused": (I, [P, I, P, P, I, P, I, I, P, P, P, P, I, I, I, I, I, I, I, I, I, P, P, P, I, P, I, P, P]),
     "unetk_conv_fwd_split": (I, [P, I, P, P, I, P, I, I, I, I, I, I, I, I, I, I, P, P, P, I, P, I, P, P]),
     "unetk_conv_wgrad_workspace_bytes": (L, [I, I, I, I, I, I, I]),
+    "unetk_conv_fwd_cat": (I, [P, I, I, P, I, P, P, I, I, I, I, I, I, I, I, P, P, P, I, P]),
+    "unetk_conv_wgrad_cat": (I, [P, I, I, P, I, P, I, P, I, I, I, I, I, I, P, L, I, P]),
     "unetk_conv_wgrad": (I, [P, I, P, I, P, I, I, I, I, I, I, I, P, L, I, P]),
     "unetk_linear_wgrad_workspace_bytes": (L, [L, I, I, I]),
     "unetk_linear_wgrad": (I, [P, I, P, I, P, P, L, I, I, I, P, L, I, P]),

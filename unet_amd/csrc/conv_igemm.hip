@@ -51,6 +51,8 @@ struct ConvArgs {
   int head_co;
   const void* resid;       // residual (same layout as out, ld = ldres) or null
   const float* resid_keep; // per-sample scale applied to the conv result before the add, or null
+  const void* in2;         // input channels >= Ci1 come from here (ld = ldin2, renumbered from 0), or null:
+  int ldin2, Ci1;          // the operand is the channel concatenation [in | in2] without ever being stored
   int ldin, ldout, ldres, ldout2, split;
   int B, H, W, Ci, Co;
   int nchunks;
@@ -82,7 +84,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
-template <typename T, int NT, int KS, bool HDB, bool FUSE>
+template <typename T, int NT, int KS, bool HDB, bool FUSE, bool TWO>
 __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
   using M = MMA<T>;
   constexpr int KC = M::KC;
@@ -165,7 +167,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
   constexpr bool HTAB = HDB || sizeof(T) == 2;
   const int slot0 = ((lane & 3) ^ swz(lane >> 2)) * EPP;
   const unsigned rows_left = (KS == 3) ? 0u : (unsigned)((npix - p0 < 256) ? (npix - p0) : 256);
-  int hp_off[HPW];
+  // (two tables when the operand is a concatenation of two tensors with different pixel strides: the
+  // second one costs registers only in the instantiations launched with it)
+  int hp_off[HPW], hp_off2[TWO ? HPW : 1];
   bool hp_in[HPW];
 #pragma unroll
   for (int k = 0; k < (HTAB ? HPW : 0); ++k) {
@@ -173,33 +177,44 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     if (KS == 3) {
       const int hy = pix / HALO, hx = pix - hy * HALO;
       hp_off[k] = (hy * a.W + hx) * a.ldin + slot0;
+      if constexpr (TWO) hp_off2[k] = (hy * a.W + hx) * a.ldin2 + slot0;
       hp_in[k] = pix < HPIX && (unsigned)(y0 - 1 + hy) < (unsigned)a.H && (unsigned)(x0 - 1 + hx) < (unsigned)a.W;
     } else {
       hp_off[k] = pix * a.ldin + slot0;
+      if constexpr (TWO) hp_off2[k] = pix * a.ldin2 + slot0;
       hp_in[k] = (unsigned)pix < rows_left;
     }
   }
   // first halo pixel of the tile (may lie outside the image: only valid lanes add to it)
   const T* halo_base = (KS == 3) ? in + (((long)b * a.H + (y0 - 1)) * a.W + (x0 - 1)) * a.ldin : in + p0 * a.ldin;
+  const T* in2 = reinterpret_cast<const T*>(a.in2);
+  const T* halo_base2 = !TWO ? nullptr
+                        : (KS == 3) ? in2 + (((long)b * a.H + (y0 - 1)) * a.W + (x0 - 1)) * a.ldin2 : in2 + p0 * a.ldin2;
   auto issue_halo = [&](int ch) {
     char* dst = lds + (RING3 ? ch % 3 : (HDB ? (ch & 1) : 0)) * HBUF;
-    const int c0 = ch * KC;
-    const T* base = halo_base + c0;
-    const int climit = a.Ci - c0;                         // channel slots below this exist
+    int c0 = ch * KC;
+    bool second = false;
+    if constexpr (TWO) second = c0 >= a.Ci1;              // (uniform; Ci1 is a multiple of the chunk)
+    if (second) c0 -= a.Ci1;
+    const T* base = (second ? halo_base2 : halo_base) + c0;
+    const int climit = (TWO ? (second ? a.Ci - a.Ci1 : a.Ci1) : a.Ci) - c0;   // channel slots below this exist
     if constexpr (!HTAB) {
       for (int i = wave; i < HINSTR; i += 4) {
         const int part = i * 64 + lane;
         const int pix = part >> 2;
-        const int c = c0 + ((part & 3) ^ swz(pix)) * EPP;
+        const int cs = ((part & 3) ^ swz(pix)) * EPP;
+        const int c = c0 + cs;
+        const T* from = second ? in2 : in;
+        const int ld = second ? a.ldin2 : a.ldin;
         const T* src = zero;
         if (KS == 3) {
           const int hy = pix / HALO, hx = pix - hy * HALO;
           const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-          if (pix < HPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.Ci)
-            src = in + (((long)b * a.H + gy) * a.W + gx) * a.ldin + c;
+          if (pix < HPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && cs < climit)
+            src = from + (((long)b * a.H + gy) * a.W + gx) * ld + c;
         } else {
           const long p = p0 + pix;
-          if (p < npix && c < a.Ci) src = in + p * a.ldin + c;
+          if (p < npix && cs < climit) src = from + p * ld + c;
         }
         glds16(src, dst + i * 1024);
       }
@@ -211,7 +226,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     for (int k = 0; k < HPW; ++k) {
       const int i = wave + 4 * k;
       if (i < HINSTR) {
-        const T* src = (hp_in[k] && chan_ok) ? halo_base + (unsigned)(hp_off[k] + c0) : zero;
+        const int off = (TWO && second) ? hp_off2[k] : hp_off[k];
+        const T* src = (hp_in[k] && chan_ok) ? (second ? halo_base2 : halo_base) + (unsigned)(off + c0) : zero;
         glds16(src, dst + i * 1024);
       }
     }
@@ -640,17 +656,17 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
   }
 }
 
-template <typename T, int NT, int KS, bool FUSE = false>
+template <typename T, int NT, int KS, bool FUSE = false, bool TWO = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_igemm_kernel(ConvArgs a) {
-  conv_igemm_body<T, NT, KS, true, FUSE>(a);
+  conv_igemm_body<T, NT, KS, true, FUSE, TWO>(a);
 }
 
 // Narrow layers move more bytes per flop than the MFMA-bound wide ones: they trade the second halo
 // buffer and registers for four workgroups per CU, so more loads are in flight.
-template <typename T, int NT, int KS, bool FUSE = false>
+template <typename T, int NT, int KS, bool FUSE = false, bool TWO = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_igemm_occ4_kernel(
     ConvArgs a) {
-  conv_igemm_body<T, NT, KS, false, FUSE>(a);
+  conv_igemm_body<T, NT, KS, false, FUSE, TWO>(a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1207,7 +1223,7 @@ __global__ void pack_weights_batched_kernel(const long* __restrict__ jobs, const
 // no residual, GELU or split-output epilogue)
 inline bool use_p48(const ConvArgs& a, int bn) {
   static const bool off = getenv("UNETK_NO_P48") != nullptr;
-  return bn == 48 && a.Co <= 48 && a.Ci > 32 && a.Ci <= 48 && !off && a.resid == nullptr && a.out2 == nullptr &&
+  return bn == 48 && a.Co <= 48 && a.Ci > 32 && a.Ci <= 48 && !off && a.resid == nullptr && a.out2 == nullptr && a.in2 == nullptr &&
          a.act <= 1 && (int64_t)a.W * a.ldin * 36 < (1LL << 31);
 }
 inline int p48_items(const ConvArgs& a) { return a.B * cdiv(a.H, 32) * cdiv(a.W, 16); }
@@ -1246,6 +1262,21 @@ int launch_conv(ConvArgs a, int bn, hipStream_t stream) {
         case 48: hipLaunchKernelGGL((conv_igemm_occ4_kernel<T, 3, KS, true>), grid, dim3(256), 0, stream, a); break;
         case 64: hipLaunchKernelGGL((conv_igemm_kernel<T, 4, KS, true>), grid, dim3(256), 0, stream, a); break;
         case 96: hipLaunchKernelGGL((conv_igemm_kernel<T, 6, KS, true>), grid, dim3(256), 0, stream, a); break;
+        default:
+          unetk_set_error("conv: unsupported channel block %d (32, 48, 64 or 96)", bn);
+          return UNETK_EINVAL;
+      }
+      UNETK_CHECK_LAUNCH();
+      return UNETK_OK;
+    }
+  }
+  if constexpr (KS == 3) {
+    if (a.in2 != nullptr) {        // the operand is [in | in2]
+      switch (bn) {
+        case 32: hipLaunchKernelGGL((conv_igemm_occ4_kernel<T, 2, KS, false, true>), grid, dim3(256), 0, stream, a); break;
+        case 48: hipLaunchKernelGGL((conv_igemm_occ4_kernel<T, 3, KS, false, true>), grid, dim3(256), 0, stream, a); break;
+        case 64: hipLaunchKernelGGL((conv_igemm_kernel<T, 4, KS, false, true>), grid, dim3(256), 0, stream, a); break;
+        case 96: hipLaunchKernelGGL((conv_igemm_kernel<T, 6, KS, false, true>), grid, dim3(256), 0, stream, a); break;
         default:
           unetk_set_error("conv: unsupported channel block %d (32, 48, 64 or 96)", bn);
           return UNETK_EINVAL;
@@ -1338,16 +1369,45 @@ int unetk_conv_num_tiles(int B, int H, int W, int ks) {
 int unetk_conv_stats_rows(int B, int H, int W, int Ci, int Co, int ks, int bn, int dtype, int ldin, int act) {
   if (ks == 3 && dtype == UNETK_BF16) {
     ConvArgs a = {};
-    a.B = B; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.ldin = ldin; a.act = act;
+    a.B = B; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.ldin = ldin; a.act = act; a.tiles_x = cdiv(W, 16);
     if (use_p48(a, bn)) return p48_stats_rows(a);
   }
   return unetk_conv_num_tiles(B, H, W, ks);
 }
 
+static int conv_fwd_impl(const void* in, int ldin, const void* in2, int ldin2, int Ci1, const void* wpacked, void* out,
+                         int ldout, void* out2, int ldout2, int split, void* pooled, const float* head_w,
+                         const float* head_b, float* head_out, int head_co, int B, int H, int W, int Ci, int Co, int ks,
+                         int bn, int dtype, float* stats, const float* ep_scale, const float* ep_shift, int act,
+                         const void* resid, int ldres, const float* resid_keep, hipStream_t stream);
+
 int unetk_conv_fwd_fused(const void* in, int ldin, const void* wpacked, void* out, int ldout, void* out2,
                          int ldout2, int split, void* pooled, const float* head_w, const float* head_b,
                          float* head_out, int head_co, int B, int H, int W, int Ci, int Co, int ks, int bn,
                          int dtype, float* stats, const float* ep_scale, const float* ep_shift, int act,
+                         const void* resid, int ldres, const float* resid_keep, hipStream_t stream) {
+  return conv_fwd_impl(in, ldin, nullptr, 0, 0, wpacked, out, ldout, out2, ldout2, split, pooled, head_w, head_b, head_out,
+                       head_co, B, H, W, Ci, Co, ks, bn, dtype, stats, ep_scale, ep_shift, act, resid, ldres, resid_keep,
+                       stream);
+}
+
+int unetk_conv_fwd_cat(const void* in, int ldin, int Ci1, const void* in2, int ldin2, const void* wpacked, void* out,
+                       int ldout, int B, int H, int W, int Ci, int Co, int bn, int dtype, float* stats,
+                       const float* ep_scale, const float* ep_shift, int act, hipStream_t stream) {
+  UNETK_CHECK_ARG(in2 != nullptr, "conv_fwd_cat: null second input");
+  const int epp = epp_of(dtype), kc = kc_of(dtype);
+  UNETK_CHECK_ARG(Ci1 > 0 && Ci1 < Ci && Ci1 % kc == 0, "conv_fwd_cat: the first input must hold a multiple of %d channels (%d of %d)", kc, Ci1, Ci);
+  UNETK_CHECK_ARG(ldin >= Ci1 && ldin2 >= Ci - Ci1 && ldin2 % epp == 0 && ((uintptr_t)in2 % 16) == 0 &&
+                  (int64_t)W * ldin2 * 20 + ldin2 < (1LL << 31),
+                  "conv_fwd_cat: second input misaligned, too narrow or too wide");
+  return conv_fwd_impl(in, ldin, in2, ldin2, Ci1, wpacked, out, ldout, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0,
+                       B, H, W, Ci, Co, 3, bn, dtype, stats, ep_scale, ep_shift, act, nullptr, 0, nullptr, stream);
+}
+
+static int conv_fwd_impl(const void* in, int ldin, const void* in2, int ldin2, int Ci1, const void* wpacked, void* out,
+                         int ldout, void* out2, int ldout2, int split, void* pooled, const float* head_w,
+                         const float* head_b, float* head_out, int head_co, int B, int H, int W, int Ci, int Co, int ks,
+                         int bn, int dtype, float* stats, const float* ep_scale, const float* ep_shift, int act,
                          const void* resid, int ldres, const float* resid_keep, hipStream_t stream) {
   UNETK_CHECK_ARG(in && wpacked && (out || head_out), "conv_fwd: null pointer");
   UNETK_CHECK_ARG((pooled == nullptr && head_out == nullptr) || (ks == 3 && resid == nullptr && out2 == nullptr),
@@ -1372,7 +1432,7 @@ int unetk_conv_fwd_fused(const void* in, int ldin, const void* wpacked, void* ou
   } else {
     UNETK_CHECK_ARG(ldout >= Co, "conv_fwd: stride smaller than channel count");
   }
-  UNETK_CHECK_ARG(ldin >= Ci, "conv_fwd: stride smaller than channel count");
+  UNETK_CHECK_ARG(ldin >= (in2 ? Ci1 : Ci), "conv_fwd: stride smaller than channel count");
   UNETK_CHECK_ARG((int64_t)W * ldin * 20 + ldin < (1LL << 31) && 256LL * ldin < (1LL << 31),
                   "conv_fwd: a halo of the input spans 2^31 elements or more");
   UNETK_CHECK_ARG(((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)wpacked % 16) == 0,
@@ -1381,6 +1441,7 @@ int unetk_conv_fwd_fused(const void* in, int ldin, const void* wpacked, void* ou
                   "conv_fwd: residual misaligned");
   ConvArgs a;
   a.in = in; a.w = wpacked; a.out = out; a.stats = stats;
+  a.in2 = in2; a.ldin2 = ldin2; a.Ci1 = Ci1;
   a.out2 = out2; a.ldout2 = ldout2; a.split = out2 ? split : 0;
   a.pooled = pooled; a.head_w = head_w; a.head_b = head_b; a.head_out = head_out; a.head_co = head_co;
   a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.resid = resid; a.resid_keep = resid_keep;

@@ -31,6 +31,8 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_dst) {
 
 struct WgradArgs {
   const void* in;
+  const void* in2;          // input channels >= Ci1 come from here (ld = ldin2, renumbered from 0), or null
+  int ldin2, Ci1;
   const void* dy;
   float* slab;
   float* bias_slab;         // [nsplit][Co_pad] column sums of dy (1x1 bf16 only), or null
@@ -137,7 +139,20 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
   const int bz = xcd_map ? ((lin >> 3) / gxy) * 8 + (lin & 7) : lin / gxy;
   const int ci0 = (cxy % a.gx) * KCI;
   const int co0 = (cxy / a.gx) * BM;
+  // the input may be the channel concatenation [in | in2] of two tensors (never stored as one): a
+  // workgroup's chunk lies in one of them (Ci1 is a multiple of the chunk)
   const T* in = reinterpret_cast<const T*>(a.in);
+  int ldin = a.ldin, sci0 = ci0, sCi = a.Ci;
+  if (a.in2 != nullptr) {
+    if (ci0 >= a.Ci1) {
+      in = reinterpret_cast<const T*>(a.in2);
+      ldin = a.ldin2;
+      sci0 = ci0 - a.Ci1;
+      sCi = a.Ci - a.Ci1;
+    } else {
+      sCi = a.Ci1;
+    }
+  }
   const T* dy = reinterpret_cast<const T*>(a.dy);
   const T* zero = reinterpret_cast<const T*>(wgrad_zero_page);
 
@@ -177,8 +192,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
     const int pix = part / PPH, slot = part - pix * PPH;
     const int hy = pix / HW_, hx = pix - hy * HW_;
     const int cs = hswz<RBH>(hx, slot) * EPP;
-    h_off[k] = (hy * a.W + hx) * a.ldin + cs;
-    h_yx[k] = (pix < HPIX && ci0 + cs < a.Ci) ? ((hy << 16) | hx) : (0x7fff << 16);
+    h_off[k] = (hy * a.W + hx) * ldin + cs;
+    h_yx[k] = (pix < HPIX && sci0 + cs < sCi) ? ((hy << 16) | hx) : (0x7fff << 16);
   }
   auto issue_tile = [&](int tile, char* dbuf) {
     int t = tile;
@@ -192,7 +207,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
     // element offsets of the tile's / halo's first pixel (the host checks that they fit 31 bits);
     // added to the lane's offset in 32 bits
     const int d0 = ((b * a.H + y0) * a.W + x0) * a.lddy + co0;
-    const int h0 = ((b * a.H + y0 - ph) * a.W + x0 - ph) * a.ldin + ci0;
+    const int h0 = ((b * a.H + y0 - ph) * a.W + x0 - ph) * ldin + sci0;
 #pragma unroll
     for (int k = 0; k < DPW; ++k) {
       int i = wave + 8 * k;
@@ -585,7 +600,7 @@ int64_t unetk_conv_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Co, in
 
 static int wgrad_impl(const void* in, int ldin, const void* dy, int lddy, float* dw, float* dbias, int B, int H, int W,
                       int Ci, int Co, int ks, int dtype, void* workspace, int64_t workspace_bytes,
-                      int accumulate, hipStream_t stream) {
+                      int accumulate, hipStream_t stream, const void* in2 = nullptr, int ldin2 = 0, int Ci1 = 0) {
   UNETK_CHECK_ARG(in && dy && dw && workspace, "conv_wgrad: null pointer");
   UNETK_CHECK_ARG(ks == 1 || ks == 3, "conv_wgrad: kernel size %d (1 or 3)", ks);
   UNETK_CHECK_ARG(dtype == UNETK_F32 || dtype == UNETK_BF16, "conv_wgrad: bad dtype %d", dtype);
@@ -602,6 +617,13 @@ static int wgrad_impl(const void* in, int ldin, const void* dy, int lddy, float*
   UNETK_CHECK_ARG(workspace_bytes >= need, "conv_wgrad: workspace %lld < %lld bytes",
                   (long long)workspace_bytes, (long long)need);
   WgradArgs a;
+  if (in2 != nullptr) {
+    const int kci = p.nwn == 1 ? 64 : p.nwn * 16;
+    UNETK_CHECK_ARG(ks == 3 && Ci1 > 0 && Ci1 < Ci && Ci1 % kci == 0 && ldin >= Ci1 && ldin2 >= Ci - Ci1 &&
+                    ldin2 % epp == 0 && ((uintptr_t)in2 % 16) == 0 && (int64_t)B * H * W * ldin2 < (1LL << 31),
+                    "conv_wgrad_cat: the first input must hold a multiple of %d channels (%d of %d), the second be aligned", kci, Ci1, Ci);
+  }
+  a.in2 = in2; a.ldin2 = ldin2; a.Ci1 = Ci1;
   a.in = in; a.dy = dy; a.slab = (float*)workspace; a.bias_slab = dbias ? (float*)((char*)workspace + main_bytes) : nullptr; a.ldin = ldin; a.lddy = lddy;
   a.B = B; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.Ci_pad = p.Ci_pad; a.Co_pad = p.Co_pad;
   a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.ntiles = p.ntiles; a.nsplit = p.nsplit;
@@ -625,6 +647,14 @@ int unetk_conv_wgrad(const void* in, int ldin, const void* dy, int lddy, float* 
                      int accumulate, hipStream_t stream) {
   return wgrad_impl(in, ldin, dy, lddy, dw, nullptr, B, H, W, Ci, Co, ks, dtype, workspace, workspace_bytes,
                     accumulate, stream);
+}
+
+int unetk_conv_wgrad_cat(const void* in, int ldin, int Ci1, const void* in2, int ldin2, const void* dy, int lddy,
+                         float* dw, int B, int H, int W, int Ci, int Co, int dtype, void* workspace,
+                         int64_t workspace_bytes, int accumulate, hipStream_t stream) {
+  UNETK_CHECK_ARG(in2 != nullptr, "conv_wgrad_cat: null second input");
+  return wgrad_impl(in, ldin, dy, lddy, dw, nullptr, B, H, W, Ci, Co, 3, dtype, workspace, workspace_bytes, accumulate,
+                    stream, in2, ldin2, Ci1);
 }
 
 int64_t unetk_linear_wgrad_workspace_bytes(int64_t npix, int Ci, int Co, int dtype) {

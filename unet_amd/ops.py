@@ -152,6 +152,26 @@ def pack_many(weights, dt):
     return [PackedConv._view(m, flat, dt) for m in metas]
 
 
+def conv_fwd_cat(x1: torch.Tensor, x2: torch.Tensor, pw: PackedConv, want_stats: bool = False, scale=None, shift=None,
+                 act: int = 0):
+    """3x3 conv of the channel concatenation [x1 | x2] (both (B,H,W,C) NHWC, read in place: the concatenated
+    tensor is never stored).  x1 must hold a multiple of the packing chunk (32 bf16 / 16 f32 channels)."""
+    B, H, W, C1 = x1.shape
+    C2 = x2.shape[-1]
+    dt = x1.dtype
+    Ci, Co = C1 + C2, pad_channels(pw.Co, dt)
+    if x2.shape[:3] != x1.shape[:3] or x2.dtype != dt or pw.ks != 3 or pad_channels(pw.Ci, dt) != Ci:
+        raise ValueError("conv_fwd_cat: the two inputs and the packed weight do not fit together")
+    out = torch.empty((B, H, W, Co), dtype=dt, device=x1.device)
+    stats = None
+    if want_stats:
+        nt = _lib.load().unetk_conv_num_tiles(B, H, W, 3)
+        stats = torch.empty((nt, 2, Co), dtype=torch.float32, device=x1.device)
+    call("unetk_conv_fwd_cat", ptr(x1), x1.stride(2), C1, ptr(x2), x2.stride(2), ptr(pw.data), ptr(out), Co, B, H, W,
+         Ci, Co, pw.bn, dtype_code(dt), ptr(stats), ptr(scale), ptr(shift), act, stream())
+    return out, stats
+
+
 def conv_fwd(x: torch.Tensor, pw: PackedConv, Ci: Optional[int] = None, Co: Optional[int] = None,
              out: Optional[torch.Tensor] = None, want_stats: bool = False, scale=None, shift=None,
              act: int = 0, resid=None, resid_keep=None, split: int = 0, pool: bool = False, head=None,
@@ -285,10 +305,14 @@ def linear_wgrad(x: torch.Tensor, dy: torch.Tensor, Ci: int, Co: int, want_bias:
     return dw, db
 
 
-def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, Ci: int, Co: int, ks: int,
+def conv_wgrad(x, dy: torch.Tensor, Ci: int, Co: int, ks: int,
                dw: Optional[torch.Tensor] = None, accumulate: bool = False,
                workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """dw (Co,Ci,k,k) fp32 from NHWC activations x (B,H,W,ldx) and output gradient dy (B,H,W,lddy)."""
+    """dw (Co,Ci,k,k) fp32 from NHWC activations x (B,H,W,ldx) and output gradient dy (B,H,W,lddy).  x may be a
+    pair (x1, x2): the layer's input was their channel concatenation (3x3 only, see conv_fwd_cat)."""
+    x2 = None
+    if isinstance(x, (tuple, list)):
+        x, x2 = x
     B, H, W, _ = x.shape
     ldx = x.stride(2)
     dt = x.dtype
@@ -301,9 +325,14 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, Ci: int, Co: int, ks: int,
     tgt = dw
     if dw is None or padded:
         tgt = torch.empty((Cop, Cip, ks, ks), dtype=torch.float32, device=x.device)
-    call("unetk_conv_wgrad", ptr(x), ldx, ptr(dy), dy.stride(2), ptr(tgt), B, H, W, Cip, Cop, ks,
-         dtype_code(dt), ptr(workspace), workspace.numel() * workspace.element_size(),
-         1 if (accumulate and not padded and dw is not None) else 0, stream())
+    acc_flag = 1 if (accumulate and not padded and dw is not None) else 0
+    if x2 is not None:
+        call("unetk_conv_wgrad_cat", ptr(x), ldx, x.shape[-1], ptr(x2), x2.stride(2), ptr(dy), dy.stride(2), ptr(tgt),
+             B, H, W, Cip, Cop, dtype_code(dt), ptr(workspace), workspace.numel() * workspace.element_size(), acc_flag,
+             stream())
+    else:
+        call("unetk_conv_wgrad", ptr(x), ldx, ptr(dy), dy.stride(2), ptr(tgt), B, H, W, Cip, Cop, ks,
+             dtype_code(dt), ptr(workspace), workspace.numel() * workspace.element_size(), acc_flag, stream())
     if padded:
         res = tgt[:Co, :Ci]
         if dw is not None:
@@ -417,6 +446,14 @@ def upsample_into(low, cat):
     call("unetk_upsample_concat_fwd", ptr(low), h, w, C1, None, 0, C - C1, ptr(cat), B, H, W,
          dtype_code(low.dtype), stream())
     return cat
+
+
+def upsample(low, H, W):
+    """bilinear_resize(low -> H,W) (align_corners=False) as a dense (B,H,W,C) tensor."""
+    B, h, w, C1 = low.shape
+    out = torch.empty((B, H, W, C1), dtype=low.dtype, device=low.device)
+    call("unetk_upsample_concat_fwd", ptr(low), h, w, C1, None, 0, 0, ptr(out), B, H, W, dtype_code(low.dtype), stream())
+    return out
 
 
 def upsample_bwd(dcat, C1, h, w):

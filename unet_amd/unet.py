@@ -126,6 +126,13 @@ def _pack_all(model, dt, transpose):
     return tuple(dicts) if transpose == "both" else dicts[0]
 
 
+def _reads_pair(up_channels: int) -> bool:
+    """Whether a decoder block's first conv (and its weight gradient) can read the resized tensor and the skip
+    tensor as two operands instead of their concatenation: the first one has to fill whole 32-channel chunks
+    of the kernels' K loop."""
+    return up_channels > 0 and up_channels % 32 == 0 and os.environ.get("UNETK_CONCAT_COPY", "0") == "0"
+
+
 class EvalEngine:
     """Inference path with BatchNorm folded into the convolution epilogues and Dropout off.
 
@@ -149,9 +156,13 @@ class EvalEngine:
 
     def _block(self, name, t, out=None, pool=False, head=None):
         """Two conv+BN+ReLU units; the second can also hand back the max-pooled output, or only
-        the network's final 1x1 conv of it (both computed in its epilogue)."""
+        the network's final 1x1 conv of it (both computed in its epilogue).  ``t`` may be the pair
+        (resized, skip) that the reference concatenates: it is then read in place."""
         sc, sh = self.fold[(name, 0)]
-        t, _ = ops.conv_fwd(t, self.pk[(name, 0)], scale=sc, shift=sh, act=1)
+        if isinstance(t, tuple):
+            t, _ = ops.conv_fwd_cat(t[0], t[1], self.pk[(name, 0)], scale=sc, shift=sh, act=1)
+        else:
+            t, _ = ops.conv_fwd(t, self.pk[(name, 0)], scale=sc, shift=sh, act=1)
         sc, sh = self.fold[(name, 3)]
         if pool or head is not None:
             return ops.conv_fwd(t, self.pk[(name, 3)], scale=sc, shift=sh, act=1, out=out, pool=pool, head=head,
@@ -159,27 +170,39 @@ class EvalEngine:
         return ops.conv_fwd(t, self.pk[(name, 3)], scale=sc, shift=sh, act=1, out=out)[0]
 
     def _encoder(self, name, dec, t):
-        """An encoder block writes straight into the skip half of its decoder's concat buffer."""
+        """An encoder block's output is the skip input of its decoder: kept as a dense tensor that the
+        decoder's first conv reads next to the resized one (no concatenated copy), or, when the channel
+        counts do not allow that, written straight into the skip half of a concat buffer."""
         seq, dseq = getattr(self.model, name), getattr(self.model, dec)
         C2 = seq[3].out_channels
         C1 = dseq[0].in_channels - C2
         B, H, W, _ = t.shape
+        if _reads_pair(C1):
+            skip, pooled, _ = self._block(name, t, pool=True)
+            return skip, pooled
         cat = torch.empty((B, H, W, C1 + C2), dtype=t.dtype, device=t.device)
         _, pooled, _ = self._block(name, t, out=cat[..., C1:], pool=True)
         return cat, pooled
 
     def __call__(self, h):
-        cat1, p = self._encoder("encoder1", "decoder1", h)
-        cat2, p = self._encoder("encoder2", "decoder2", p)
-        cat3, p = self._encoder("encoder3", "decoder3", p)
-        cat4, p = self._encoder("encoder4", "decoder4", p)
+        s1, p = self._encoder("encoder1", "decoder1", h)
+        s2, p = self._encoder("encoder2", "decoder2", p)
+        s3, p = self._encoder("encoder3", "decoder3", p)
+        s4, p = self._encoder("encoder4", "decoder4", p)
         d = self._block("bottleneck", p)
-        for name, cat in (("decoder4", cat4), ("decoder3", cat3), ("decoder2", cat2)):
-            d = self._block(name, ops.upsample_into(d, cat))
+
+        def joined(name, enc, d, s):
+            C1 = getattr(self.model, name)[0].in_channels - getattr(self.model, enc)[3].out_channels
+            if _reads_pair(C1):
+                return (ops.upsample(d, s.shape[1], s.shape[2]), s)
+            return ops.upsample_into(d, s)
+
+        for name, enc, s in (("decoder4", "encoder4", s4), ("decoder3", "encoder3", s3), ("decoder2", "encoder2", s2)):
+            d = self._block(name, joined(name, enc, d, s))
         last = self.pk[("decoder1", 3)]
         if last.Co <= last.bn:           # the head needs every channel in one workgroup
-            return self._block("decoder1", ops.upsample_into(d, cat1), head=(self.head_w, self.head_b))[2]
-        d = self._block("decoder1", ops.upsample_into(d, cat1))
+            return self._block("decoder1", joined("decoder1", "encoder1", d, s1), head=(self.head_w, self.head_b))[2]
+        d = self._block("decoder1", joined("decoder1", "encoder1", d, s1))
         return ops.head1x1_fwd(d, self.head_w, self.head_b)
 
 
@@ -209,7 +232,10 @@ class _UNetTrainFn(torch.autograd.Function):
             pooled = argmax = cat = None
             for u, (ci, bi) in enumerate(((0, 1), (3, 4))):
                 bn = seq[bi]
-                y, stats = ops.conv_fwd(t, pk[(name, ci)], want_stats=True)
+                if isinstance(t, tuple):       # (resized, skip): the concatenation the reference stores
+                    y, stats = ops.conv_fwd_cat(t[0], t[1], pk[(name, ci)], want_stats=True)
+                else:
+                    y, stats = ops.conv_fwd(t, pk[(name, ci)], want_stats=True)
                 Bn, H, W, C = y.shape
                 mean, invstd, sc, sh = ops.bn_finalize(
                     stats, Bn * H * W, bn.weight, bn.bias,
@@ -219,7 +245,10 @@ class _UNetTrainFn(torch.autograd.Function):
                 if bn.track_running_stats:
                     bn.num_batches_tracked += 1
                 last = u == 1
-                if last and pool:
+                if last and pool and _reads_pair(cat_c1):
+                    a, pooled, argmax = ops.bn_act_fwd(y, sc, sh, keep, relu=True, pool=True, want_argmax=True)
+                    cat = a                    # the skip tensor itself: its decoder reads it in place
+                elif last and pool:
                     cat = torch.empty((Bn, H, W, cat_c1 + C), dtype=y.dtype, device=y.device)
                     a, pooled, argmax = ops.bn_act_fwd(y, sc, sh, keep, relu=True, pool=True,
                                                        out=cat[..., cat_c1:], want_argmax=True)
@@ -242,8 +271,11 @@ class _UNetTrainFn(torch.autograd.Function):
                                          ("decoder1", cat1))):
             low_hw = d.shape[1:3]
             saved[name + ".low"] = (low_hw, d.shape[3])
-            ops.upsample_into(d, cat)
-            d, _, _ = block(name, cat, masks[5 + i], False)
+            if _reads_pair(d.shape[3]):
+                joined = (ops.upsample(d, cat.shape[1], cat.shape[2]), cat)
+            else:
+                joined = ops.upsample_into(d, cat)
+            d, _, _ = block(name, joined, masks[5 + i], False)
         saved["head_in"] = d
         out = ops.head1x1_fwd(d, model.conv.weight, model.conv.bias)
         ctx.model = model
