@@ -141,13 +141,14 @@ def timed(fn, steps, warmup, world, dev):
 
 
 class ConvTimer:
-    """Brackets every implicit-GEMM launch that goes through ops.conv_fwd (3x3 convs forward and data
-    gradient, and the 1x1 / linear layers) with events on the launch stream."""
+    """Brackets every implicit-GEMM launch that goes through ops.conv_fwd / ops.conv_fwd_cat (3x3 convs forward
+    and data gradient, and the 1x1 / linear layers) with events on the launch stream."""
 
     def __init__(self):
         from unet_amd import ops
         self.ops = ops
         self.orig = ops.conv_fwd
+        self.orig_cat = ops.conv_fwd_cat
         self.records = []
 
     def __enter__(self):
@@ -164,11 +165,26 @@ class ConvTimer:
                                 bytes=float(npix * (pw.Ci + pw.Co) * esz + pw.data.numel() * esz)))
             return r
 
+        orig_cat = self.orig_cat
+
+        def timed_conv_cat(x1, x2, pw, *a, **k):      # the decoder convs that read (resized, skip) in place
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig_cat(x1, x2, pw, *a, **k)
+            e1.record()
+            npix = x1.numel() // x1.shape[-1]
+            esz = x1.element_size()
+            records.append(dict(e0=e0, e1=e1, flops=2.0 * npix * pw.Co * pw.Ci * pw.ks * pw.ks, bn=pw.bn, ks=pw.ks,
+                                bytes=float(npix * (pw.Ci + pw.Co) * esz + pw.data.numel() * esz)))
+            return r
+
         self.ops.conv_fwd = timed_conv
+        self.ops.conv_fwd_cat = timed_conv_cat
         return self
 
     def __exit__(self, *exc):
         self.ops.conv_fwd = self.orig
+        self.ops.conv_fwd_cat = self.orig_cat
 
     def family(self, pred):
         rows = [(r["e0"].elapsed_time(r["e1"]), r["flops"], r["bytes"]) for r in self.records if pred(r)]

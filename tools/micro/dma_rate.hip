@@ -39,6 +39,12 @@ int main() {
     {"64-B runs at stride 64 B (contiguous, 4 lanes a run), 1 GiB", 64, 4, bytes},
     {"64-B runs at stride 288 B, 32 MiB", 288, 4, 32L << 20},
     {"128-B runs at stride 288 B, 1 GiB", 288, 8, bytes},
+    {"64-B runs at stride 192 B, 32 MiB", 192, 4, 32L << 20},
+    {"64-B runs at stride 384 B, 32 MiB", 384, 4, 32L << 20},
+    {"128-B runs at stride 384 B, 32 MiB", 384, 8, 32L << 20},
+    {"256-B runs at stride 768 B, 32 MiB", 768, 16, 32L << 20},
+    {"64-B runs at stride 128 B, 32 MiB", 128, 4, 32L << 20},
+    {"96-B runs at stride 192 B (6 lanes a run), 32 MiB", 192, 6, 32L << 20},
   };
   for (auto& m : modes) {
     const int iters = 2048;
