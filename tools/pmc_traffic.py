@@ -33,6 +33,20 @@ for k in sorted(fetch, key=lambda k: -fetch[k]):
     wr = write[k] / nw[k] * 1024
     out[k] = {"launches_sampled": nf[k], "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
               "hbm_bytes_per_launch": round(rd + wr)}
+# Instantiations that differ only in bool template flags ("name<...>+01") are also summed under the bare
+# name when there are several of them: bench.py prices a kernel family as one (all its launches per step).
+fam = defaultdict(list)
+for k in out:
+    fam[k.split("+")[0]].append(k)
+for base, ks in fam.items():
+    if len(ks) > 1:
+        n = sum(out[k]["launches_sampled"] for k in ks)
+        rd = sum(out[k]["read_bytes_per_launch"] * out[k]["launches_sampled"] for k in ks) / n
+        wr = sum(out[k]["write_bytes_per_launch"] * out[k]["launches_sampled"] for k in ks) / n
+        if base in out:
+            out[base + "+plain"] = out[base]
+        out[base] = {"launches_sampled": n, "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
+                     "hbm_bytes_per_launch": round(rd + wr), "variants": sorted(k for k in ks if k != base) + [base + "+plain"]}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 for k, v in list(out.items())[:12]:
     print(k, v)

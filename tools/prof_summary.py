@@ -14,7 +14,9 @@ def short(n):
     m = re.match(r'_ZN12_GLOBAL__N_1\d+([a-z0-9_]+?)I(DF16b|f)(.*)E+v', n)
     if m:
         ints = re.findall(r'Li(\d+)E', m.group(3))
-        return f"{m.group(1)}<{'bf16' if m.group(2) == 'DF16b' else 'f32'}{''.join(',' + i for i in ints)}>"
+        flags = re.findall(r'Lb([01])E', m.group(3))       # bool template arguments: shown only when one is set
+        tail = ("+" + "".join(flags)) if "1" in flags else ""
+        return f"{m.group(1)}<{'bf16' if m.group(2) == 'DF16b' else 'f32'}{''.join(',' + i for i in ints)}>{tail}"
     m = re.match(r'(?:void )?([a-z0-9_]+)<(__hip_bfloat16|float)((?:, \d+)*)(?:, (?:true|false))*>', n)
     if m:
         return f"{m.group(1)}<{'bf16' if m.group(2) != 'float' else 'f32'}{m.group(3).replace(' ', '')}>"
