@@ -165,10 +165,14 @@ def test_train_forward_backward_bf16(golden, name):
 
 
 def test_bf16_loss_curve_tracks_fp32():
-    """The regime that matters: a learnable target (a fixed smooth function of the input), 20 optimiser
+    """The regime that matters: a learnable target (a fixed smooth function of the input), 40 optimiser
     steps from the same initialisation in fp32 and in bf16 storage, while the loss falls by a factor of ~40.
     The two loss curves must agree within 10 % at every step and within 4 % on average, and both must learn
-    (final loss below a tenth of the first)."""
+    (final loss below a tenth of the first).  The learning rate is 3e-4: at 1e-3 the fp32 path's own response
+    to a 1e-6 relative perturbation of the input reaches 8 % of the loss in the late steps (20 % at 5e-4 over
+    30 steps), so a per-step comparison there measures the optimiser's noise, not the storage precision
+    (tools/exp_curve.py prints both); the fp32 self-deviation is measured here too and must stay below the
+    bf16 bound, so that the comparison means something."""
     from unet_amd import OptimizedUNet
     from unet_amd.optim import FusedAdamW
     torch.manual_seed(7)
@@ -177,27 +181,32 @@ def test_bf16_loss_curve_tracks_fp32():
     x = x / x.std()
     y = torch.tanh(0.8 * x[:, :1] - 0.6 * x[:, 1:2] * x[:, 2:3]) + 0.3 * F.avg_pool2d(F.pad(x[:, 3:4], (1, 1, 1, 1)), 3, 1)
     init = OptimizedUNet(4, 1, 16).state_dict()
-    curves = {}
-    for dt in (torch.float32, torch.bfloat16):
+    noise = torch.randn_like(x)
+
+    def run(dt, eps=0.0):
         m = OptimizedUNet(4, 1, 16, compute_dtype=dt)
         m.load_state_dict(init)
         m = m.cuda().train()
         m.dropout_masks_override = [None] * 9
-        opt = FusedAdamW(m.parameters(), lr=1e-3, weight_decay=5e-5, max_grad_norm=1.0)
-        xd, yd = x.cuda(), y.cuda()
+        opt = FusedAdamW(m.parameters(), lr=3e-4, weight_decay=5e-5, max_grad_norm=1.0)
+        xd, yd = (x * (1 + eps * noise)).cuda(), y.cuda()
         losses = []
-        for _ in range(20):
+        for _ in range(40):
             opt.zero_grad()
             loss = ((m(xd) - yd) ** 2).mean()
             loss.backward()
             opt.step()
             losses.append(loss.item())
-        curves[dt] = np.array(losses)
-    f32, b16 = curves[torch.float32], curves[torch.bfloat16]
+        return np.array(losses)
+
+    f32, b16, f32_eps = run(torch.float32), run(torch.bfloat16), run(torch.float32, 1e-6)
     dev = np.abs(b16 - f32) / f32
+    self_dev = np.abs(f32_eps - f32) / f32
     print("fp32 loss curve", np.round(f32, 4).tolist())
-    print("bf16 loss curve", np.round(b16, 4).tolist(), "max deviation", dev.max())
+    print("bf16 loss curve", np.round(b16, 4).tolist(), "max deviation", dev.max(), "mean", dev.mean(),
+          "; fp32 against itself with 1e-6 input noise: max", self_dev.max())
     assert f32[-1] < 0.1 * f32[0] and b16[-1] < 0.1 * b16[0]
+    assert self_dev.max() < 0.10, self_dev
     assert dev.max() < 0.10 and dev.mean() < 0.04, dev
 
 

@@ -150,74 +150,86 @@ __global__ void bn_fold_eval_kernel(const float* gamma, const float* beta, const
 // buffer (row stride lda); argmax (nullable) receives, per pooled element, the position 0..3
 // (row-major in the quad) of its first maximum, which is all the pooling backward needs.
 template <typename T>
-__global__ void bn_act_fwd_kernel(const T* __restrict__ y, int ldy, T* __restrict__ a, int lda,
-                                  T* __restrict__ pooled,
-                                  unsigned char* __restrict__ argmax, int B, int H, int W, int C,
-                                  const float* __restrict__ scale, const float* __restrict__ shift,
-                                  const float* __restrict__ keep, int relu) {
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, int ldy, T* __restrict__ a, int lda,
+                                                         T* __restrict__ pooled,
+                                                         unsigned char* __restrict__ argmax, int B, int H, int W, int C,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         const float* __restrict__ keep, int relu, unsigned chunk) {
+  // Threads are (quad lane, channel group): a thread keeps its channel group's scale and shift in
+  // registers and walks the quads of the workgroup's chunk, sample by sample (the Dropout2d keep
+  // factors are per sample and channel).
   constexpr int E = Vec16<T>::N;
   const int CG = C / E;
+  const int lanes = 256 / CG;
+  const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
+  if (pl >= lanes) return;
   const int QH = (H + 1) >> 1, QW = (W + 1) >> 1;
-  const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;     // the host checks that it fits 31 bits
-  const unsigned total = (unsigned)B * QH * QW * CG;
-  if (idx >= total) return;
-  const int cg = idx % CG;
-  unsigned t = idx / CG;
-  const int qx = t % QW;
-  t /= QW;
-  const int qy = t % QH;
-  const int b = t / QH;
+  const unsigned qhw = (unsigned)QH * QW, nquads = (unsigned)B * qhw;
   const int c0 = cg * E;
-  float sc[E], sh[E], kp[E];
+  float sc[E], sh[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     sc[e] = scale ? scale[c0 + e] : 1.f;
     sh[e] = shift ? shift[c0 + e] : 0.f;
-    kp[e] = keep ? keep[(long)b * C + c0 + e] : 1.f;
   }
-  float mx[E];
-  unsigned char arg[E];
+  const unsigned qbeg = blockIdx.x * chunk;
+  unsigned qend = qbeg + chunk;
+  if (qend > nquads) qend = nquads;
+  unsigned seg = qbeg;
+  while (seg < qend) {
+    const unsigned b = seg / qhw;
+    unsigned seg_end = (b + 1) * qhw;
+    if (seg_end > qend || seg_end < seg) seg_end = qend;
+    float kp[E];
 #pragma unroll
-  for (int e = 0; e < E; ++e) {
-    mx[e] = -INFINITY;
-    arg[e] = 0;
-  }
+    for (int e = 0; e < E; ++e) kp[e] = keep ? keep[(size_t)b * C + c0 + e] : 1.f;
+    for (unsigned qi = seg + pl; qi < seg_end; qi += lanes) {
+      const unsigned r = qi - b * qhw;
+      const int qy = r / QW, qx = r - qy * QW;
+      const bool row1 = 2 * qy + 1 < H, col1 = 2 * qx + 1 < W;
+      const long p00 = ((long)b * H + 2 * qy) * W + 2 * qx;
+      // the (up to) four pixels of the quad: all loads first
+      Vec16<T> v[4];
+      v[0] = load16(y + p00 * ldy + c0);
+      if (col1) v[1] = load16(y + (p00 + 1) * ldy + c0);
+      if (row1) v[2] = load16(y + (p00 + W) * ldy + c0);
+      if (row1 && col1) v[3] = load16(y + (p00 + W + 1) * ldy + c0);
+      float mx[E];
+      unsigned char arg[E];
 #pragma unroll
-  for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-    for (int dx = 0; dx < 2; ++dx) {
-      const int yy = 2 * qy + dy, xx = 2 * qx + dx;
-      if (yy < H && xx < W) {
-        const long pix = ((long)b * H + yy) * W + xx;
-        Vec16<T> v = load16(y + pix * ldy + c0);
+      for (int k = 0; k < 4; ++k) {
+        const bool ok = (k & 1 ? col1 : true) && (k & 2 ? row1 : true);
+        if (!ok) continue;
         Vec16<T> o;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-          float z = to_f32(v.v[e]) * sc[e] + sh[e];
+          float z = to_f32(v[k].v[e]) * sc[e] + sh[e];
           if (relu) z = fmaxf(z, 0.f);
           z *= kp[e];
           o.v[e] = from_f32<T>(z);
           const float zr = to_f32(o.v[e]);
-          if (zr > mx[e] || (dy == 0 && dx == 0)) {   // strict '>': the first maximum in scan order
+          if (k == 0 || zr > mx[e]) {         // strict '>': the first maximum in scan order
             mx[e] = zr;
-            arg[e] = (unsigned char)(2 * dy + dx);
+            arg[e] = (unsigned char)k;
           }
         }
-        if (a != nullptr) store16(a + pix * lda + c0, o);
+        if (a != nullptr) store16(a + (p00 + (k & 1) + (k & 2 ? W : 0)) * lda + c0, o);
+      }
+      if (pooled != nullptr && row1 && col1) {
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < E; ++e) o.v[e] = from_f32<T>(mx[e]);
+        const long q = (((long)b * (H >> 1) + qy) * (W >> 1) + qx) * C + c0;
+        store16(pooled + q, o);
+        if (argmax != nullptr) {
+#pragma unroll
+          for (int e = 0; e < E; e += 4)
+            *reinterpret_cast<unsigned int*>(argmax + q + e) =
+                arg[e] | (arg[e + 1] << 8) | (arg[e + 2] << 16) | ((unsigned)arg[e + 3] << 24);
+        }
       }
     }
-  if (pooled != nullptr && 2 * qy + 1 < H && 2 * qx + 1 < W) {
-    Vec16<T> o;
-#pragma unroll
-    for (int e = 0; e < E; ++e) o.v[e] = from_f32<T>(mx[e]);
-    const long q = (((long)b * (H >> 1) + qy) * (W >> 1) + qx) * C + c0;
-    store16(pooled + q, o);
-    if (argmax != nullptr) {
-#pragma unroll
-      for (int e = 0; e < E; e += 4)
-        *reinterpret_cast<unsigned int*>(argmax + q + e) =
-            arg[e] | (arg[e + 1] << 8) | (arg[e + 2] << 16) | ((unsigned)arg[e + 3] << 24);
-    }
+    seg = seg_end;
   }
 }
 
@@ -246,11 +258,7 @@ __global__ __launch_bounds__(256) void bn_act_stream_kernel(const T* __restrict_
   const unsigned pbeg = blockIdx.x * chunk;
   unsigned pend = pbeg + chunk;
   if (pend > npix) pend = npix;
-  for (unsigned p = pbeg + pl; p < pend; p += lanes) {
-    Vec16<T> v = load16(y + (size_t)p * ldy + c0);
-    float kp[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) kp[e] = keep ? keep[(size_t)(p / hw) * C + c0 + e] : 1.f;
+  auto one = [&](unsigned p, const Vec16<T>& v, const float (&kp)[E]) {
     Vec16<T> o;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -259,6 +267,24 @@ __global__ __launch_bounds__(256) void bn_act_stream_kernel(const T* __restrict_
       o.v[e] = from_f32<T>(z * kp[e]);
     }
     store16(a + (size_t)p * lda + c0, o);
+  };
+  // sample by sample: the Dropout2d keep factors are per (sample, channel), loaded once per segment
+  unsigned seg = pbeg;
+  while (seg < pend) {
+    const unsigned b = seg / hw;
+    unsigned seg_end = (b + 1) * hw;
+    if (seg_end > pend || seg_end < seg) seg_end = pend;
+    float kp[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) kp[e] = keep ? keep[(size_t)b * C + c0 + e] : 1.f;
+    unsigned p = seg + pl;
+    for (; p + lanes < seg_end; p += 2 * lanes) {     // two pixels in flight
+      const Vec16<T> v0 = load16(y + (size_t)p * ldy + c0), v1 = load16(y + (size_t)(p + lanes) * ldy + c0);
+      one(p, v0, kp);
+      one(p + lanes, v1, kp);
+    }
+    if (p < seg_end) one(p, load16(y + (size_t)p * ldy + c0), kp);
+    seg = seg_end;
   }
 }
 
@@ -351,7 +377,17 @@ __global__ __launch_bounds__(RED_THREADS) void channel_reduce_kernel(RedArgs a) 
           }
           if (p < seg_end) one(load16(x + p * a.ldx + c0), gen(p));
         } else {
-        for (; p + lanes < seg_end; p += 2 * lanes) {   // two pixels in flight
+        for (; p + 3 * lanes < seg_end; p += 4 * lanes) {   // four pixels (eight loads) in flight
+          const Vec16<T> x0 = load16(x + p * a.ldx + c0), g0 = load16(gp + p * a.ldg + c0);
+          const Vec16<T> x1 = load16(x + (p + lanes) * a.ldx + c0), g1 = load16(gp + (p + lanes) * a.ldg + c0);
+          const Vec16<T> x2 = load16(x + (p + 2 * lanes) * a.ldx + c0), g2 = load16(gp + (p + 2 * lanes) * a.ldg + c0);
+          const Vec16<T> x3 = load16(x + (p + 3 * lanes) * a.ldx + c0), g3 = load16(gp + (p + 3 * lanes) * a.ldg + c0);
+          one(x0, g0);
+          one(x1, g1);
+          one(x2, g2);
+          one(x3, g3);
+        }
+        for (; p + lanes < seg_end; p += 2 * lanes) {
           const Vec16<T> x0 = load16(x + p * a.ldx + c0), g0 = load16(gp + p * a.ldg + c0);
           const Vec16<T> x1 = load16(x + (p + lanes) * a.ldx + c0), g1 = load16(gp + (p + lanes) * a.ldg + c0);
           one(x0, g0);
@@ -516,24 +552,17 @@ __global__ __launch_bounds__(RED_THREADS) void bn_act_bwd_apply_kernel(
   float wv[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) wv[e] = g1_d != nullptr ? g1_w[c0 + e] : 0.f;
-  for (unsigned p = pbeg + pl; p < pend; p += lanes) {
-    const size_t off = (size_t)p * C + c0;
-    Vec16<T> gv;
+  auto gload = [&](unsigned p) {
     if (g1_d != nullptr) {      // (uniform) rank-one gradient formed on the fly
       const float d = g1_d[p];
+      Vec16<T> gv;
 #pragma unroll
       for (int e = 0; e < E; ++e) gv.v[e] = from_f32<T>(d * wv[e]);
-    } else {
-      gv = load16(g + off);
+      return gv;
     }
-    Vec16<T> yv = load16(y + off);
-    float kp[E];
-    if (keep != nullptr) {
-      load_params<E>(keep + (size_t)(p / hw) * C + c0, kp);
-    } else {
-#pragma unroll
-      for (int e = 0; e < E; ++e) kp[e] = 1.f;
-    }
+    return load16(g + (size_t)p * C + c0);
+  };
+  auto one = [&](unsigned p, const Vec16<T>& gv, const Vec16<T>& yv, const float (&kp)[E]) {
     Vec16<T> o;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -542,7 +571,30 @@ __global__ __launch_bounds__(RED_THREADS) void bn_act_bwd_apply_kernel(
       if (relu && !(yy * sc[e] + sh[e] > 0.f)) dz = 0.f;
       o.v[e] = from_f32<T>(sc[e] * dz + k1[e] * yy + k0[e]);
     }
-    store16(dy + off, o);
+    store16(dy + (size_t)p * C + c0, o);
+  };
+  // sample by sample: the Dropout2d keep factors are per (sample, channel), loaded once per segment
+  unsigned seg = pbeg;
+  while (seg < pend) {
+    const unsigned b = seg / hw;
+    unsigned seg_end = (b + 1) * hw;
+    if (seg_end > pend || seg_end < seg) seg_end = pend;
+    float kp[E];
+    if (keep != nullptr) {
+      load_params<E>(keep + (size_t)b * C + c0, kp);
+    } else {
+#pragma unroll
+      for (int e = 0; e < E; ++e) kp[e] = 1.f;
+    }
+    unsigned p = seg + pl;
+    for (; p + lanes < seg_end; p += 2 * lanes) {     // two pixels (four loads) in flight
+      const Vec16<T> g0 = gload(p), y0 = load16(y + (size_t)p * C + c0);
+      const Vec16<T> g1 = gload(p + lanes), y1 = load16(y + (size_t)(p + lanes) * C + c0);
+      one(p, g0, y0, kp);
+      one(p + lanes, g1, y1, kp);
+    }
+    if (p < seg_end) one(p, gload(p), load16(y + (size_t)p * C + c0), kp);
+    seg = seg_end;
   }
 }
 
@@ -1059,11 +1111,18 @@ int unetk_bn_act_fwd(const void* y, int ldy, void* a, int lda, void* pooled, uns
     UNETK_CHECK_LAUNCH();
     return UNETK_OK;
   }
-  const long total = (long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / E);
-  UNETK_CHECK_ARG(total < (1L << 31), "bn_act_fwd: tensor too large");
-  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3(cdiv(total, 256)), dim3(256), 0, stream,
-                                       (const T*)y, ldy, (T*)a, lda, (T*)pooled, argmax, B, H, W, C, scale, shift,
-                                       keep, relu));
+  const long nquads = (long)B * ((H + 1) / 2) * ((W + 1) / 2);
+  UNETK_CHECK_ARG(nquads * (C / E) < (1L << 31) && npix < (1L << 31) && C / E <= 256, "bn_act_fwd: tensor too large");
+  {
+    const int lanes = 256 / (C / E);
+    long nb = (nquads + (long)lanes * 4 - 1) / ((long)lanes * 4);
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    const unsigned chunk = (unsigned)((nquads + nb - 1) / nb);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3((unsigned)cdiv(nquads, chunk)), dim3(256), 0, stream,
+                                         (const T*)y, ldy, (T*)a, lda, (T*)pooled, argmax, B, H, W, C, scale, shift,
+                                         keep, relu, chunk));
+  }
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }
