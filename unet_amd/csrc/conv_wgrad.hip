@@ -450,14 +450,15 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
 // 32-channel chunk), all taps: R*taps*32 elements (R = 8 for 1x1, 1 for 3x3).  Each thread sums one
 // element over the slabs in a fixed order (bitwise reproducible) reading 128-byte runs along ci, the
 // tile turns in LDS, and the results leave as one contiguous run of dw per output channel.
-constexpr int WR_MAX = 288;     // elements per workgroup: 9 taps x 32 channels, or 8 rows x 32 channels
+constexpr int WR_ROWS3 = 4;                      // output channels per workgroup, 3x3
+constexpr int WR_MAX = WR_ROWS3 * 288;           // elements per workgroup: rows x (9 taps x 32 channels), or 8 rows x 32 channels
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab,
                                                            float* __restrict__ dw, int nslab, int Co, int Ci,
                                                            int Co_pad, int Ci_pad, int taps,
                                                            int accumulate, int nmain,
                                                            const float* __restrict__ bias_slab,
                                                            float* __restrict__ db) {
-  __shared__ float tile[WR_MAX];
+  __shared__ __attribute__((aligned(16))) float tile[WR_MAX];
   if ((int)blockIdx.x >= nmain) {
     // trailing workgroups: db[co] (+)= sum_s bias_slab[s][co], slabs in a fixed order
     const int co = (blockIdx.x - nmain) * 256 + threadIdx.x;
@@ -468,26 +469,28 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
     return;
   }
-  const int R = taps == 1 ? 8 : 1;
+  const int R = taps == 1 ? 8 : WR_ROWS3;
   const int nchunk = Ci_pad / 32;
   const int chunk = blockIdx.x % nchunk;
   const int co0 = (blockIdx.x / nchunk) * R;
   const int per_row = taps * 32, nel = R * per_row;
   const long stride = (long)Co_pad * taps * Ci_pad;
-  for (int e = threadIdx.x; e < nel; e += 256) {
+  // four consecutive input channels per thread (16-byte loads), four slabs in flight, summed in slab order
+  for (int e = threadIdx.x * 4; e < nel; e += 1024) {
     const int row = e / per_row, rem = e - row * per_row;
     const int tap = rem >> 5, cl = rem & 31;
-    float s = 0.f;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (co0 + row < Co) {
       const float* p = slab + ((long)(co0 + row) * taps + tap) * Ci_pad + chunk * 32 + cl;
       int i = 0;
-      for (; i + 4 <= nslab; i += 4) {       // four loads in flight, summed in slab order
-        const float v0 = p[i * stride], v1 = p[(i + 1) * stride], v2 = p[(i + 2) * stride], v3 = p[(i + 3) * stride];
+      for (; i + 4 <= nslab; i += 4) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + i * stride), v1 = *reinterpret_cast<const f32x4*>(p + (i + 1) * stride);
+        const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (i + 2) * stride), v3 = *reinterpret_cast<const f32x4*>(p + (i + 3) * stride);
         s = (((s + v0) + v1) + v2) + v3;
       }
-      for (; i < nslab; ++i) s += p[i * stride];
+      for (; i < nslab; ++i) s += *reinterpret_cast<const f32x4*>(p + i * stride);
     }
-    tile[e] = s;
+    *reinterpret_cast<f32x4*>(tile + e) = s;
   }
   __syncthreads();
   for (int e = threadIdx.x; e < nel; e += 256) {
@@ -634,7 +637,7 @@ static int wgrad_impl(const void* in, int ldin, const void* dy, int lddy, float*
   else
     rc = ks == 3 ? launch_wgrad<float, 3>(a, p, stream) : launch_wgrad<float, 1>(a, p, stream);
   if (rc != UNETK_OK) return rc;
-  const long nblocks = (long)cdiv(Co, ks == 1 ? 8 : 1) * (p.Ci_pad / 32);
+  const long nblocks = (long)cdiv(Co, ks == 1 ? 8 : WR_ROWS3) * (p.Ci_pad / 32);
   const long nbias = dbias ? cdiv(Co, 256) : 0;      // trailing workgroups sum the bias slabs
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(nblocks + nbias)), dim3(256), 0, stream, a.slab, dw,
                      p.nsplit, Co, Ci, p.Co_pad, p.Ci_pad, ks * ks, accumulate, (int)nblocks, a.bias_slab, dbias);

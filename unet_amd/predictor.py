@@ -259,8 +259,12 @@ class LargeAreaPredictor:
 
         # the network on this rank's tiles: the expensive part, independent of the blend order
         preds = []
-        for s in range(0, len(mine), self.device_batch):
-            ids = mine[s:s + self.device_batch]
+        # equal-sized launches (at most device_batch tiles each): no short last batch that would run the whole
+        # network for a handful of tiles
+        nlaunch = max(1, -(-len(mine) // self.device_batch))
+        per_launch = max(1, -(-len(mine) // nlaunch))
+        for s in range(0, len(mine), per_launch):
+            ids = mine[s:s + per_launch]
             out = engine(be.gather(feats, pos_d, int(ids[0]), len(ids), P, dt))
             if out.shape[1] != 1:
                 out = out[:, :1].contiguous()
