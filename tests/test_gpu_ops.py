@@ -300,7 +300,7 @@ def test_linear_wgrad_with_bias(ntok, Ci, Co):
 
 @pytest.mark.parametrize("shape", [(2, 37, 18, 48, 48), (1, 70, 50, 144, 48), (3, 33, 16, 48, 144), (1, 32, 16, 40, 40),
                                    (2, 5, 3, 8, 48), (1, 96, 64, 48, 48), (5, 64, 64, 96, 48), (40, 64, 64, 48, 48),
-                                   (3, 100, 40, 48, 40), (1, 2, 3, 48, 48)])
+                                   (3, 100, 40, 48, 40), (1, 2, 3, 48, 48), (6, 70, 50, 48, 144), (36, 64, 64, 40, 144)])
 def test_conv_48_channel_blocks_bf16(shape):
     """48-channel output blocks (bf16, 3x3), among them the persistent whole-pixel kernel that takes the layers with
     33..48 input and up to 48 output channels: ragged images, partial channel counts, one and many tiles per

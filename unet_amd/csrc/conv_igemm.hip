@@ -1155,6 +1155,291 @@ __global__ __launch_bounds__(512) void conv3x3_p48_kernel(ConvArgs a) {
 #endif
 }
 
+// The same structure for THREE 48-channel output blocks over a 33..48-channel input: the data gradient of
+// the 144 -> 48 layer.  A tile's halo serves its three blocks; what changes from block to block is the
+// weight set (42 KB), and LDS has room for one next to the two halo buffers.  So the blocks of a tile run in
+// the order 0,1,2 on even tiles and 2,1,0 on odd ones: the last block's weights stay for the next tile's
+// first, the middle block's weights are prefetched into the halo buffer that is idle during the tile's
+// first block, the last block's into the weight buffer during the middle one, and the next tile's halo
+// during the last one - every load is issued one block ahead, nothing waits.
+__global__ __launch_bounds__(512) void conv3x3_p48x3_kernel(ConvArgs a) {
+  using T = bf16;
+  using frag = bf16x8;
+  __shared__ __attribute__((aligned(256))) char halo0[P48_HBUF];
+  __shared__ __attribute__((aligned(256))) char halo1[P48_HBUF];
+  __shared__ __attribute__((aligned(256))) char wlds[P48_WBUF];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, q = lane >> 4;
+  const bool early = wave < 4;
+  const T* in = reinterpret_cast<const T*>(a.in);
+  const T* wp = reinterpret_cast<const T*>(a.w);
+  const T* zero = reinterpret_cast<const T*>(conv_zero_page);
+  const long wblock = (long)a.nchunks * 9 * 48 * 32;        // packed elements per output block
+
+  const int tiles_y32 = (a.H + 31) >> 5;
+  const int nitems = a.B * tiles_y32 * a.tiles_x;
+  const int nwg = gridDim.x;
+  const int pos = (blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3);
+  const int per = (nitems + nwg - 1) / nwg;
+  const int first = pos * per;
+  int mine = nitems - first;
+  if (mine > per) mine = per;
+  if (mine <= 0) return;
+  auto advance = [&](P48Item& it) __attribute__((always_inline)) {
+    if (++it.tx == a.tiles_x) {
+      it.tx = 0;
+      if (++it.ty == tiles_y32) {
+        it.ty = 0;
+        ++it.b;
+      }
+    }
+  };
+  P48Item nxt;
+  nxt.tx = first % a.tiles_x;
+  nxt.ty = (first / a.tiles_x) % tiles_y32;
+  nxt.b = first / a.tiles_x / tiles_y32;
+  P48Item cur = nxt;
+
+  // weight DMA: piece j = wave + 8k (step j/3, MFMA tile j%3); element offset inside a block's pack, or -1: zeros
+  constexpr int WPW = (P48_WINSTR + 7) / 8;
+  int w_off[WPW];
+  {
+    const int m = lane >> 2, slot = (lane & 3) ^ swz(m);
+#pragma unroll
+    for (int k = 0; k < WPW; ++k) {
+      const int j = wave + 8 * k;
+      const int st = j / 3, t = j - 3 * st;
+      const int chan = t < 2 ? 8 * (m >> 2) + 4 * t + (m & 3) : 32 + m;
+      if (st < 9) {
+        w_off[k] = (st * 48 + chan) * 32 + slot * 8;
+      } else {
+        const int tap = 2 * (st - 9) + (slot >> 1);
+        w_off[k] = (tap < 9 && a.nchunks > 1) ? 9 * 48 * 32 + (tap * 48 + chan) * 32 + (slot & 1) * 8 : -1;
+      }
+    }
+  }
+  auto issue_w_part = [&](char* dst, int nb, auto gc) __attribute__((always_inline)) {    // pieces 2G, 2G+1 of this wave
+    constexpr int G = decltype(gc)::value;
+    const T* base = wp + nb * wblock;
+#pragma unroll
+    for (int k = 2 * G; k < 2 * G + 2 && k < WPW; ++k) {
+      const int j = wave + 8 * k;
+      if (j < P48_WINSTR) glds16(w_off[k] >= 0 ? base + w_off[k] : zero, dst + j * 1024);
+    }
+  };
+
+  constexpr int HPW = (P48_HINSTR + 7) / 8;
+  int hp_off[HPW], hp_yx[HPW];
+#pragma unroll
+  for (int k = 0; k < HPW; ++k) {
+    const int o = (wave + 8 * k) * 1024 + lane * 16;
+    const int r = o / P48_ROWB, rem = o - r * P48_ROWB;
+    const int px = rem / P48_PIXB, cb = rem - px * P48_PIXB;
+    hp_off[k] = (r * a.W + px) * a.ldin + (cb >> 1);
+    hp_yx[k] = o >= P48_HBYTES ? (int)0x80000000 : ((cb >> 1) < a.Ci ? ((r << 16) | px) : (0x4000 << 16));
+  }
+  const T* hbase = nullptr;
+  int iy0 = 0, ix0 = 0;
+  auto issue_h_begin = [&]() __attribute__((always_inline)) {
+    iy0 = nxt.ty * 32 - 1;
+    ix0 = nxt.tx * 16 - 1;
+    hbase = in + (((long)nxt.b * a.H + iy0) * a.W + ix0) * a.ldin;
+    advance(nxt);
+  };
+  auto issue_h_part = [&](char* hdst, auto gc) __attribute__((always_inline)) {
+    constexpr int G = decltype(gc)::value;
+#pragma unroll
+    for (int k = 2 * G; k < 2 * G + 2 && k < HPW; ++k) {
+      const int i = wave + 8 * k;
+      if (i < P48_HINSTR && hp_yx[k] >= 0) {
+        const int hy = hp_yx[k] >> 16, hx = hp_yx[k] & 0xffff;
+        const bool ok = (unsigned)(iy0 + hy) < (unsigned)a.H && (unsigned)(ix0 + hx) < (unsigned)a.W;
+        glds16(ok ? hbase + hp_off[k] : zero, hdst + i * 1024);
+      }
+    }
+  };
+
+  const int p_lane = (4 * wave * 18 + l15) * P48_PIXB + 16 * q;
+  int t_lane[5];
+#pragma unroll
+  for (int p = 0; p < 5; ++p) {
+    int tap = 2 * p + (q >> 1);
+    if (tap > 8) tap = 8;
+    t_lane[p] = (4 * wave * 18 + l15 + (tap / 3) * 18 + tap % 3) * P48_PIXB + 64 + 16 * (q & 1);
+  }
+  const int w_lane = l15 * ROWB + ((q ^ swz(l15)) * 16);
+
+  f32x4 acc[4][3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  frag wf[3][3];
+  auto load_wcol = [&](const char* wbuf, auto kxc) __attribute__((always_inline)) {
+    constexpr int kx = decltype(kxc)::value;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        wf[ky][t] = *reinterpret_cast<const frag*>(wbuf + w_lane + (((ky * 3 + kx) * 48 + t * 16) * ROWB));
+  };
+  auto col_rows = [&](const char* halo, auto kxc, auto r0c, auto r1c) __attribute__((always_inline)) {
+    constexpr int kx = decltype(kxc)::value, R0 = decltype(r0c)::value, R1 = decltype(r1c)::value;
+    frag pf[R1 - R0];
+#pragma unroll
+    for (int r = R0; r < R1; ++r) pf[r - R0] = *reinterpret_cast<const frag*>(halo + p_lane + (r * 18 + kx) * P48_PIXB);
+#pragma unroll
+    for (int r = R0; r < R1; ++r) {
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int i = r - ky;
+        if (i >= 0 && i < 4) {
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ky][t], pf[r - R0], acc[i][t], 0, 0, 0);
+        }
+      }
+    }
+  };
+  auto tails = [&](const char* halo, const char* wbuf, auto p0c, auto p1c) __attribute__((always_inline)) {
+    constexpr int P0 = decltype(p0c)::value, P1 = decltype(p1c)::value;
+#pragma unroll
+    for (int p = P0; p < P1; ++p) {
+      frag wt[3], pf[4];
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        wt[t] = *reinterpret_cast<const frag*>(wbuf + w_lane + (((9 + p) * 48 + t * 16) * ROWB));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pf[i] = *reinterpret_cast<const frag*>(halo + t_lane[p] + i * 18 * P48_PIXB);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[t], pf[i], acc[i][t], 0, 0, 0);
+    }
+  };
+
+  // the finished block: results packed to bf16 (pk), stored during the next block
+  uint32_t pk[4][6];
+  P48Item done = cur;
+  int done_nb = 0;
+  bool pending = false;
+  const bool relu = a.act == 1;
+  auto finish_block = [&](int nb) __attribute__((always_inline)) {
+    done = cur;
+    done_nb = nb;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        f32x4 v = acc[i][t];
+        if (relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        pk[i][2 * t] = p48_pack2(v[0], v[1]);
+        pk[i][2 * t + 1] = p48_pack2(v[2], v[3]);
+        acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    pending = true;
+  };
+  auto store_part = [&](auto gc) __attribute__((always_inline)) {
+    constexpr int G = decltype(gc)::value;
+    const int n0 = done_nb * 48;
+    T* obase = reinterpret_cast<T*>(a.out);
+    int ldo = a.ldout, oc = n0;
+    if (a.out2 != nullptr && n0 >= a.split) {
+      obase = reinterpret_cast<T*>(a.out2);
+      ldo = a.ldout2;
+      oc = n0 - a.split;
+    }
+    const int gx = done.tx * 16 + l15;
+    const int gy = done.ty * 32 + 4 * wave + G;
+    if (gy < a.H && gx < a.W) {
+      T* dst = obase + (((long)done.b * a.H + gy) * a.W + gx) * ldo + oc;
+      if (n0 + 8 * q < a.Co) *reinterpret_cast<u32x4*>(dst + 8 * q) = u32x4{pk[G][0], pk[G][1], pk[G][2], pk[G][3]};
+      if (n0 + 32 + 4 * q < a.Co) *reinterpret_cast<uint2*>(dst + 32 + 4 * q) = uint2{pk[G][4], pk[G][5]};
+    }
+  };
+
+  // one block of one tile.  P: the halo buffer of the tile; K: 0 first, 1 middle, 2 last block of the tile
+  // (weights in wlds / the other halo buffer / wlds); the side job loads what the NEXT block needs.
+  auto block = [&](auto parc, auto kc, int nb, int nb_next, bool more_tiles) __attribute__((always_inline)) {
+    constexpr int P = decltype(parc)::value, K = decltype(kc)::value;
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    using I5 = std::integral_constant<int, 5>;
+    using I6 = std::integral_constant<int, 6>;
+    const char* halo = P ? halo1 : halo0;
+    char* other = P ? halo0 : halo1;
+    const char* wbuf = K == 1 ? other : wlds;
+    // everything issued during the previous block has landed, and every wave is done multiplying it
+    __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
+    asm volatile("s_barrier" ::: "memory");
+    const bool st = pending;
+    pending = false;
+    if (K == 2 && more_tiles) issue_h_begin();
+    auto side = [&](auto gc) __attribute__((always_inline)) {
+      if constexpr (K == 0) issue_w_part(other, nb_next, gc);
+      if constexpr (K == 1) issue_w_part(wlds, nb_next, gc);
+      if constexpr (K == 2) {
+        if (more_tiles) issue_h_part(other, gc);
+      }
+      if (st) store_part(gc);
+    };
+    load_wcol(wbuf, I0{});
+    if (early) side(I0{});
+    col_rows(halo, I0{}, I0{}, I3{});
+    if (!early) side(I0{});
+    col_rows(halo, I0{}, I3{}, I6{});
+    load_wcol(wbuf, I1{});
+    if (early) side(I1{});
+    col_rows(halo, I1{}, I0{}, I3{});
+    if (!early) side(I1{});
+    col_rows(halo, I1{}, I3{}, I6{});
+    load_wcol(wbuf, I2{});
+    if (early) side(I2{});
+    col_rows(halo, I2{}, I0{}, I3{});
+    if (!early) side(I2{});
+    col_rows(halo, I2{}, I3{}, I6{});
+    if (early) side(I3{});
+    tails(halo, wbuf, I0{}, I2{});
+    if (!early) side(I3{});
+    tails(halo, wbuf, I2{}, I5{});
+    finish_block(nb);
+  };
+  auto tile = [&](auto parc, int s) __attribute__((always_inline)) {
+    const bool fwd = (s & 1) == 0;
+    const int b0 = fwd ? 0 : 2, b2 = fwd ? 2 : 0;
+    block(parc, std::integral_constant<int, 0>{}, b0, 1, true);
+    block(parc, std::integral_constant<int, 1>{}, 1, b2, true);
+    block(parc, std::integral_constant<int, 2>{}, b2, b2, s + 1 < mine);
+    advance(cur);
+  };
+
+  // prologue: the first tile's halo and its first block's weights
+  issue_h_begin();
+  issue_h_part(halo0, std::integral_constant<int, 0>{});
+  issue_h_part(halo0, std::integral_constant<int, 1>{});
+  issue_h_part(halo0, std::integral_constant<int, 2>{});
+  issue_h_part(halo0, std::integral_constant<int, 3>{});
+  issue_w_part(wlds, 0, std::integral_constant<int, 0>{});
+  issue_w_part(wlds, 0, std::integral_constant<int, 1>{});
+  issue_w_part(wlds, 0, std::integral_constant<int, 2>{});
+#pragma unroll 1
+  for (int s = 0; s < mine; s += 2) {
+    tile(std::integral_constant<int, 0>{}, s);
+    if (s + 1 < mine) tile(std::integral_constant<int, 1>{}, s + 1);
+  }
+  store_part(std::integral_constant<int, 0>{});
+  store_part(std::integral_constant<int, 1>{});
+  store_part(std::integral_constant<int, 2>{});
+  store_part(std::integral_constant<int, 3>{});
+}
+
 // ---- weight packing: [Co][Ci][KS][KS] f32 -> [nblk][nchunk][tap][BN][KC] T
 template <typename T>
 __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ dst, int Co, int Ci,
@@ -1245,6 +1530,18 @@ int launch_conv(ConvArgs a, int bn, hipStream_t stream) {
   a.nby = cdiv(a.Co, bn);
   dim3 grid((unsigned)(8 * a.tiles_per_xcd * a.nby));
   if constexpr (KS == 3 && sizeof(T) == 2) {
+    if (a.nby == 3 && a.stats == nullptr && a.ep_scale == nullptr && a.ep_shift == nullptr && a.pooled == nullptr &&
+        a.head_out == nullptr && (a.out2 == nullptr || a.split % 48 == 0)) {
+      // three 48-channel output blocks over a narrow input (the data gradient of the 144 -> 48 layer)
+      ConvArgs b = a;
+      b.Co = 48;
+      b.out2 = nullptr;
+      if (use_p48(b, bn)) {
+        hipLaunchKernelGGL(conv3x3_p48x3_kernel, dim3(p48_workgroups(b)), dim3(512), 0, stream, a);
+        UNETK_CHECK_LAUNCH();
+        return UNETK_OK;
+      }
+    }
     if (use_p48(a, bn)) {
       const int nwg = p48_workgroups(a);
       if (a.pooled != nullptr || a.head_out != nullptr)
