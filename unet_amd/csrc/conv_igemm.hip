@@ -813,16 +813,15 @@ __global__ __launch_bounds__(512) void conv3x3_p48_kernel(ConvArgs a) {
     hbase = in + (((long)nxt.b * a.H + iy0) * a.W + ix0) * a.ldin;
     advance(nxt);
   };
-  auto issue_part = [&](auto parc, auto gc) __attribute__((always_inline)) {       // pieces 2G, 2G+1 of this wave
-    constexpr int P = decltype(parc)::value, G = decltype(gc)::value;
+  auto issue_piece = [&](auto parc, auto kc) __attribute__((always_inline)) {       // piece wave + 8K of the halo image
+    constexpr int P = decltype(parc)::value, K = decltype(kc)::value;
     char* hdst = P ? halo1 : halo0;
-#pragma unroll
-    for (int k = 2 * G; k < 2 * G + 2 && k < HPW; ++k) {
-      const int i = wave + 8 * k;
-      if (i < P48_HINSTR && hp_yx[k] >= 0) {
-        const int hy = hp_yx[k] >> 16, hx = hp_yx[k] & 0xffff;
+    if constexpr (K < HPW) {
+      const int i = wave + 8 * K;
+      if (i < P48_HINSTR && hp_yx[K] >= 0) {
+        const int hy = hp_yx[K] >> 16, hx = hp_yx[K] & 0xffff;
         const bool ok = (unsigned)(iy0 + hy) < (unsigned)a.H && (unsigned)(ix0 + hx) < (unsigned)a.W;
-        glds16(ok ? hbase + hp_off[k] : zero, hdst + i * 1024);
+        glds16(ok ? hbase + hp_off[K] : zero, hdst + i * 1024);
       }
     }
   };
@@ -1037,16 +1036,19 @@ __global__ __launch_bounds__(512) void conv3x3_p48_kernel(ConvArgs a) {
       for (int t = 0; t < 3; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     pending = true;
   };
-  // row G of the finished tile's result
-  auto store_part = [&](auto gc) __attribute__((always_inline)) {
-    constexpr int G = decltype(gc)::value;
+  // row G of the finished tile's result: its 16-byte part (HALF = 0) or its 8-byte part (HALF = 1)
+  auto store_piece = [&](auto gc, auto hc) __attribute__((always_inline)) {
+    constexpr int G = decltype(gc)::value, HALF = decltype(hc)::value;
     if (a.out == nullptr) return;
     const int gy = done.ty * 32 + 4 * wave + G;
     const int gx = done.tx * 16 + l15;
     if (gy < a.H && gx < a.W) {
       T* dst = reinterpret_cast<T*>(a.out) + (((long)done.b * a.H + gy) * a.W + gx) * a.ldout;
-      if (8 * q < a.Co) *reinterpret_cast<u32x4*>(dst + 8 * q) = u32x4{pk[G][0], pk[G][1], pk[G][2], pk[G][3]};
-      if (32 + 4 * q < a.Co) *reinterpret_cast<uint2*>(dst + 32 + 4 * q) = uint2{pk[G][4], pk[G][5]};
+      if constexpr (HALF == 0) {
+        if (8 * q < a.Co) *reinterpret_cast<u32x4*>(dst + 8 * q) = u32x4{pk[G][0], pk[G][1], pk[G][2], pk[G][3]};
+      } else {
+        if (32 + 4 * q < a.Co) *reinterpret_cast<uint2*>(dst + 32 + 4 * q) = uint2{pk[G][4], pk[G][5]};
+      }
     }
   };
 
@@ -1055,10 +1057,7 @@ __global__ __launch_bounds__(512) void conv3x3_p48_kernel(ConvArgs a) {
   const long tstart = __builtin_readcyclecounter();
 #endif
   issue_begin();
-  issue_part(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-  issue_part(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
-  issue_part(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
-  issue_part(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
+  static_for<HPW>([&](auto kc) { issue_piece(std::integral_constant<int, 0>{}, kc); });
   auto tile_step = [&](auto parc, int s) __attribute__((always_inline)) {
     constexpr int P = decltype(parc)::value;
     using PN = std::integral_constant<int, P ^ 1>;
@@ -1086,32 +1085,46 @@ __global__ __launch_bounds__(512) void conv3x3_p48_kernel(ConvArgs a) {
     const bool st = pending;
     pending = false;
     if (more) issue_begin();
-    auto side = [&](auto gc) __attribute__((always_inline)) {
+    // Sixteen side operations per tile - the eight DMA pieces of the next tile's halo, then the eight store
+    // instructions of the previous tile's result - one in front of (waves 0..3) or behind (waves 4..7) each
+    // group of 9 or 12 MFMAs: the address path sees a steady trickle instead of bursts that every wave queues in.
+    auto side_op = [&](auto nc) __attribute__((always_inline)) {
+      constexpr int N = decltype(nc)::value;
       STAMP(4)
-      if (more) issue_part(PN{}, gc);
-      STAMP(2)
-      if (st) store_part(gc);
-      STAMP(3)
+      if constexpr (N < 8) {
+        if (more) issue_piece(PN{}, nc);
+        STAMP(2)
+      } else {
+        if (st) store_piece(std::integral_constant<int, (N - 8) / 2>{}, std::integral_constant<int, (N - 8) % 2>{});
+        STAMP(3)
+      }
     };
+#define P48_GROUP(N, ...)                                          \
+    if (early) side_op(std::integral_constant<int, N>{});          \
+    __VA_ARGS__;                                                   \
+    if (!early) side_op(std::integral_constant<int, N>{});
+    using I4 = std::integral_constant<int, 4>;
     load_wcol(I0{});
-    if (early) side(I0{});
-    col_rows(parc, I0{}, I0{}, I3{});
-    if (!early) side(I0{});
-    col_rows(parc, I0{}, I3{}, I6{});
+    P48_GROUP(0, col_rows(parc, I0{}, I0{}, I2{}))
+    P48_GROUP(1, col_rows(parc, I0{}, I2{}, I3{}))
+    P48_GROUP(2, col_rows(parc, I0{}, I3{}, I4{}))
+    P48_GROUP(3, col_rows(parc, I0{}, I4{}, I6{}))
     load_wcol(I1{});
-    if (early) side(I1{});
-    col_rows(parc, I1{}, I0{}, I3{});
-    if (!early) side(I1{});
-    col_rows(parc, I1{}, I3{}, I6{});
+    P48_GROUP(4, col_rows(parc, I1{}, I0{}, I2{}))
+    P48_GROUP(5, col_rows(parc, I1{}, I2{}, I3{}))
+    P48_GROUP(6, col_rows(parc, I1{}, I3{}, I4{}))
+    P48_GROUP(7, col_rows(parc, I1{}, I4{}, I6{}))
     load_wcol(I2{});
-    if (early) side(I2{});
-    col_rows(parc, I2{}, I0{}, I3{});
-    if (!early) side(I2{});
-    col_rows(parc, I2{}, I3{}, I6{});
-    if (early) side(I3{});
-    tails(parc, I0{}, I2{});
-    if (!early) side(I3{});
-    tails(parc, I2{}, I5{});
+    P48_GROUP(8, col_rows(parc, I2{}, I0{}, I2{}))
+    P48_GROUP(9, col_rows(parc, I2{}, I2{}, I3{}))
+    P48_GROUP(10, col_rows(parc, I2{}, I3{}, I4{}))
+    P48_GROUP(11, col_rows(parc, I2{}, I4{}, I6{}))
+    P48_GROUP(12, tails(parc, I0{}, I1{}))
+    P48_GROUP(13, tails(parc, I1{}, I2{}))
+    P48_GROUP(14, tails(parc, I2{}, I3{}))
+    P48_GROUP(15, tails(parc, I3{}, I4{}))
+    tails(parc, I4{}, I5{});
+#undef P48_GROUP
     STAMP(4)
     finish_item();
     advance(cur);
@@ -1122,10 +1135,10 @@ __global__ __launch_bounds__(512) void conv3x3_p48_kernel(ConvArgs a) {
     tile_step(std::integral_constant<int, 0>{}, s);
     if (s + 1 < mine) tile_step(std::integral_constant<int, 1>{}, s + 1);
   }
-  store_part(std::integral_constant<int, 0>{});
-  store_part(std::integral_constant<int, 1>{});
-  store_part(std::integral_constant<int, 2>{});
-  store_part(std::integral_constant<int, 3>{});
+  static_for<4>([&](auto gc) {
+    store_piece(gc, std::integral_constant<int, 0>{});
+    store_piece(gc, std::integral_constant<int, 1>{});
+  });
   if (a.stats != nullptr) {
     // one row of partial sums per workgroup: lanes of a pixel row by DPP, the eight waves through LDS
 #pragma unroll
