@@ -83,9 +83,11 @@ def test_gelu_scale_merge_shuffle(dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("case", [(2, 16, 24, 3, 0), (2, 16, 24, 3, 4), (1, 8, 8, 6, 4), (1, 32, 8, 12, 4)])
+@pytest.mark.parametrize("case", [(2, 16, 24, 3, 0), (2, 16, 24, 3, 4), (1, 8, 8, 6, 4), (1, 32, 8, 12, 4),
+                                  (20, 64, 64, 3, 4), (5, 32, 64, 6, 0)])
 def test_window_attention_fwd_bwd(dt, case):
-    """Shifted and unshifted windows, the single-window stage (mask still applied), several heads."""
+    """Shifted and unshifted windows, the single-window stage (mask still applied), several heads; the last two
+    cases give every persistent wave of the bfloat16 kernels an uneven run of several (window, head) items."""
     from unet_amd import ops
     B, H, Wd, heads, shift = case
     C = heads * 32

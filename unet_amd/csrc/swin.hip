@@ -8,6 +8,7 @@
 // table staged in LDS, and the shift mask (-100 between different regions) is recomputed from the
 // window coordinates.  QK^T and PV (and the five products of the backward) run on MFMA from
 // LDS-staged operands; softmax is done on the accumulator registers.
+#include "attn.h"
 #include "common.h"
 #include "mma.h"
 
@@ -1114,6 +1115,10 @@ int unetk_window_attn_fwd(const void* qkv, void* out, const float* table, int B,
   UNETK_CHECK_ARG(qkv && out && table && B > 0, "window_attn_fwd: bad arguments");
   CHECK_DT("window_attn_fwd", dtype);
   if (int rc = check_attn("window_attn_fwd", He, We, C, heads, shift)) return rc;
+  if (dtype == UNETK_BF16) {      // persistent double-buffered kernels of attn.hip
+    const AttnLaunch a{qkv, nullptr, out, nullptr, table, nullptr, B, He, We, C, heads, shift, use_mask, scale};
+    return attn_bf16_fwd(a, stream);
+  }
   AttnGeom g{B, He, We, C, heads, shift, use_mask, scale};
   const int nblk = B * (He / WS) * (We / WS) * heads;
   DISPATCH_T(dtype, hipLaunchKernelGGL(window_attn_fwd_kernel<T>, dim3(nblk), dim3(64), 0, stream, (const T*)qkv,
@@ -1132,9 +1137,14 @@ int unetk_window_attn_bwd(const void* qkv, const void* dout, void* dqkv, const f
   if (int rc = check_attn("window_attn_bwd", He, We, C, heads, shift)) return rc;
   AttnGeom g{B, He, We, C, heads, shift, use_mask, scale};
   const int nwin = B * (He / WS) * (We / WS);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(window_attn_bwd_kernel<T>, dim3(nwin * heads), dim3(64), 0, stream,
-                                       (const T*)qkv, (const T*)dout, (T*)dqkv, table, dtable_partials, g));
-  UNETK_CHECK_LAUNCH();
+  if (dtype == UNETK_BF16) {
+    const AttnLaunch a{qkv, dout, nullptr, dqkv, table, dtable_partials, B, He, We, C, heads, shift, use_mask, scale};
+    if (int rc = attn_bf16_bwd(a, stream)) return rc;
+  } else {
+    hipLaunchKernelGGL(window_attn_bwd_kernel<float>, dim3(nwin * heads), dim3(64), 0, stream, (const float*)qkv,
+                       (const float*)dout, (float*)dqkv, table, dtable_partials, g);
+    UNETK_CHECK_LAUNCH();
+  }
   hipLaunchKernelGGL(dtable_reduce_kernel, dim3(225, heads), dim3(64), 0, stream, dtable_partials, nwin, heads,
                      dtable);
   UNETK_CHECK_LAUNCH();
