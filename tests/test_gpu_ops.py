@@ -85,6 +85,37 @@ def test_conv_fwd_dgrad_wgrad(dt, shape):
     assert rel(dw2.cpu(), 2 * wr.grad) < TOL[dt]
 
 
+@pytest.mark.parametrize("shape", [(1, 128, 256, 48, 0), (2, 66, 250, 48, 0), (1, 132, 256, 144, 0), (1, 128, 256, 96, 48),
+                                   (4, 47, 161, 96, 48)])
+def test_wgrad_whole_pixel_kernel(shape):
+    """The full-resolution 48-output-channel weight gradient (dense bf16 operands, one workgroup streams every pixel
+    once) against autograd and against the generic kernel; ragged sizes, one and two operands, accumulate."""
+    import os
+    from unet_amd import ops
+    dt = torch.bfloat16
+    B, H, W, C1, C2 = shape
+    Ci, Co = C1 + C2, 48
+    x = rnd((B, Ci, H, W), 61, dt)
+    gy = rnd((B, Co, H, W), 62, dt)
+    wr = torch.zeros((Co, Ci, 3, 3), requires_grad=True)
+    F.conv2d(x, wr, None, padding=1).backward(gy)
+    xd, gd = nhwc(x, dt), nhwc(gy, dt)
+    arg = (xd[..., :C1].contiguous(), xd[..., C1:].contiguous()) if C2 else xd
+    dw = ops.conv_wgrad(arg, gd, Ci, Co, 3)
+    assert rel(dw.cpu(), wr.grad) < TOL[dt]
+    os.environ["UNETK_WGRAD_NO_PX"] = "1"
+    try:
+        generic = ops.conv_wgrad(arg, gd, Ci, Co, 3)
+    finally:
+        del os.environ["UNETK_WGRAD_NO_PX"]
+    assert not torch.equal(dw, generic) and rel(dw.cpu(), generic.cpu()) < 1e-5      # another summation order
+    assert torch.equal(dw, ops.conv_wgrad(arg, gd, Ci, Co, 3))                         # and the same bits every run
+    dw2 = ops.conv_wgrad(arg, gd, Ci, Co, 3, dw=dw.clone(), accumulate=True)
+    assert rel(dw2.cpu(), 2 * wr.grad) < TOL[dt]
+    if C2:   # the stored concatenation takes the same kernel with the same unit assignment: the same bits
+        assert torch.equal(dw, ops.conv_wgrad(xd, gd, Ci, Co, 3))
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("shape", [(144, 96), (144, 48), (192, 96), (128, 64)])
 def test_conv_split_outputs(dt, shape):

@@ -17,6 +17,7 @@
 // fp32 partial into a slab [S][Co_pad][taps][Ci_pad]; a second kernel sums the slabs in a fixed
 // order (bitwise reproducible, no atomics) and writes the [Co][Ci][KS][KS] fp32 gradient.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -160,7 +161,12 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int t = 0; t < NACC + NB; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NACC + NB; ++t) {
+      acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // (opaque to the optimiser: knowing the zeros, it peels the first tile with accumulators that are
+      // not updated in place and runs out of registers in the 64-channel 3x3 form)
+      asm volatile("" : "+v"(acc[m][t]));
+    }
   const bool want_bias = NB > 0 && a.bias_slab != nullptr;
 
   const int g = lane >> 4, li = lane & 15, q = li >> 2, p4 = li & 3;
@@ -505,6 +511,320 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Whole-pixel weight gradient (bf16, 3x3, exactly 48 output channels, 48 / 96+48 / 144 dense input
+// channels): the full-resolution layers of the UNet, whose reduction runs over millions of pixels for
+// a small dw.  They are bound by bytes: the generic kernel above reads dy once per 32-channel input
+// chunk and gathers 64-byte runs a pixel stride apart (~100 cycles of the CU's address path per
+// 1 KiB DMA piece, against ~33 for a piece whose lanes cover 1 KiB of consecutive memory in any
+// order).  Here one workgroup owns ALL of dw and streams every pixel exactly once:
+//  * pixels are staged whole, so a tile row of dy (32 pixels x 96 bytes) and a halo row of an input
+//    (34 pixels x 96 / 192 / 288 bytes) are single runs and the LDS images are byte-for-byte copies;
+//  * the eight waves do not split the reduction: a wave owns up to four UNITS = (16-channel input
+//    slice, kernel row), nine accumulator tiles each (3 row blocks x 3 horizontal taps cut out of three
+//    transposing reads, as above), takes every k-step of every tile, and writes its part of the fp32
+//    slab itself - nothing is summed through LDS;
+//  * workgroup w takes the 4-row x 32-column tiles w, w + nwg, ... in image order: at any moment the chip
+//    streams one contiguous band of the image (DRAM pages and TLB entries are shared), and the tiles
+//    above and below one another, which share two halo rows, run at the same time on one XCD (tile ids a
+//    multiple of 8 apart when the image is 256 wide) and share its L2.
+template <int NS1, int NS2, int NKG>
+__global__ __launch_bounds__(512) void conv_wgrad_px_kernel(WgradArgs a) {
+  using T = bf16;
+  constexpr int MT = 3, TW = 32, TR = 4, TPIX = TW * TR, HW_ = TW + 2, HH_ = TR + 2, HPIX = HW_ * HH_;
+  constexpr int RBD = MT * 32;                         // dy row bytes = the whole pixel
+  constexpr int P1 = NS1 * 32, P2 = NS2 * 32;          // pixel pitch of the two input images
+  constexpr int DINSTR = TPIX * RBD / 1024;
+  constexpr int H1INSTR = (HPIX * P1 + 1023) / 1024, H2INSTR = (HPIX * P2 + 1023) / 1024;
+  constexpr int DBUF = DINSTR * 1024, H1BUF = H1INSTR * 1024, H2BUF = H2INSTR * 1024;
+  constexpr int STAGE = DBUF + H1BUF + H2BUF;
+  constexpr int S = (3 * STAGE <= 156 * 1024) ? 3 : 2;
+  constexpr int NINSTR = DINSTR + H1INSTR + H2INSTR, NPW = (NINSTR + 7) / 8;
+  // NKG groups of 8 / NKG waves split the tile's k-steps (few units: nine units on eight waves would leave
+  // seven of them idle half of the time); each group writes a slab of its own
+  constexpr int WPG = 8 / NKG, KPG = TR / NKG;
+  constexpr int NUNITS = (NS1 + NS2) * 3, UPW = (NUNITS + WPG - 1) / WPG;
+  static_assert(TPIX * RBD % 1024 == 0 && 2 * STAGE <= 159 * 1024 && 2 * NPW < 64 && TR % NKG == 0, "stage layout");
+  __shared__ __attribute__((aligned(1024))) char buf0[STAGE];
+  __shared__ __attribute__((aligned(1024))) char buf1[STAGE];
+  __shared__ __attribute__((aligned(1024))) char buf2[S == 3 ? STAGE : 1024];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const T* dy = reinterpret_cast<const T*>(a.dy);
+  const T* in1 = reinterpret_cast<const T*>(a.in);
+  const T* in2 = reinterpret_cast<const T*>(a.in2);
+  const T* zero = reinterpret_cast<const T*>(wgrad_zero_page);
+
+  const int nwg = gridDim.x;
+  const int pos = blockIdx.x;
+  const int n = pos < a.ntiles ? (a.ntiles - pos + nwg - 1) / nwg : 0;      // tiles of this workgroup
+
+  // ---- DMA tables: piece i = wave + 8k covers bytes [1024 i, 1024 i + 1024) of the stage (dy image, then
+  // the halo images); per piece an element offset from the tile's first (halo) pixel and the pixel's
+  // (row, column), or a row no image has
+  int p_off[NPW], p_yx[NPW];
+#pragma unroll
+  for (int k = 0; k < NPW; ++k) {
+    int i = wave + 8 * k;
+    if (i >= NINSTR) i = NINSTR - 1;
+    if (i < DINSTR) {
+      const int o = i * 1024 + lane * 16;
+      const int pix = o / RBD, byte = o - pix * RBD;
+      const int tr = pix / TW, tc = pix - tr * TW;
+      p_off[k] = (tr * a.W + tc) * a.lddy + (byte >> 1);
+      p_yx[k] = (tr << 16) | tc;
+    } else {
+      const bool second = NS2 > 0 && i >= DINSTR + H1INSTR;
+      const int o = (i - DINSTR - (second ? H1INSTR : 0)) * 1024 + lane * 16;
+      const int pitch = second ? P2 : P1;
+      const int hp = o / pitch, byte = o - hp * pitch;
+      const int hy = hp / HW_, hx = hp - hy * HW_;
+      p_off[k] = (hy * a.W + hx) * (second ? a.ldin2 : a.ldin) + (byte >> 1);
+      p_yx[k] = hp < HPIX ? ((hy << 16) | hx) : (0x7fff << 16);
+    }
+  }
+  auto issue_tile = [&](int tile, char* dbuf) {
+    if (a.gx & 2) return;
+    const int tx = tile % a.tiles_x;
+    const int t2 = tile / a.tiles_x;
+    const int ty = t2 % a.tiles_y;
+    const int b = t2 / a.tiles_y;
+    const int y0 = ty * TR, x0 = tx * TW;
+    const int d0 = ((b * a.H + y0) * a.W + x0) * a.lddy;
+    const int h1 = ((b * a.H + y0 - 1) * a.W + x0 - 1) * a.ldin;
+    const int h2 = NS2 > 0 ? ((b * a.H + y0 - 1) * a.W + x0 - 1) * a.ldin2 : 0;
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) {
+      int i = wave + 8 * k;
+      if (i >= NINSTR) i = NINSTR - 1;
+      const int py = p_yx[k] >> 16, px = p_yx[k] & 0xffff;
+      const T* src;
+      if (i < DINSTR) {
+        src = (y0 + py < a.H && x0 + px < a.W) ? dy + (unsigned)(d0 + p_off[k]) : zero;
+      } else {
+        const bool ok = (unsigned)(y0 - 1 + py) < (unsigned)a.H && (unsigned)(x0 - 1 + px) < (unsigned)a.W;
+        const bool second = NS2 > 0 && i >= DINSTR + H1INSTR;
+        src = ok ? (second ? in2 + (unsigned)(h2 + p_off[k]) : in1 + (unsigned)(h1 + p_off[k])) : zero;
+      }
+      glds16(src, dbuf + i * 1024);
+    }
+  };
+
+  // ---- this wave's units and fragment addresses
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, p4 = li & 3;
+  int a_off[MT][2];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      a_off[m][h] = ((wave / WPG) * KPG * TW + 8 * g + q + 4 * h) * RBD + (2 * m + (p4 >> 1)) * 16 + (p4 & 1) * 8;
+  int t_off[UPW], rowstep[UPW], pixstep[UPW];
+  bool uvalid[UPW];
+  const int kg = wave / WPG, wu = wave % WPG;
+#pragma unroll
+  for (int j = 0; j < UPW; ++j) {
+    const int u = wu + WPG * j;
+    uvalid[j] = u < NUNITS;
+    const int uc = uvalid[j] ? u : NUNITS - 1;
+    const int slice = uc / 3, ky = uc - 3 * slice;
+    const bool second = NS2 > 0 && slice >= NS1;
+    const int pitch = second ? P2 : P1;
+    const int sl = second ? slice - NS1 : slice;
+    t_off[j] = DBUF + (second ? H1BUF : 0) + ((kg * KPG + ky) * HW_ + 8 * g + q) * pitch + (sl * 2 + (p4 >> 1)) * 16 +
+               (p4 & 1) * 8;
+    rowstep[j] = HW_ * pitch;
+    pixstep[j] = 4 * pitch;
+  }
+
+  f32x4 acc[UPW][MT][3];
+#pragma unroll
+  for (int j = 0; j < UPW; ++j)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        acc[j][m][kx] = f32x4{0.f, 0.f, 0.f, 0.f};
+        asm volatile("" : "+v"(acc[j][m][kx]));      // (see the generic kernel)
+      }
+
+  auto multiply = [&](const char* lds) {
+    if (a.gx & 1) return;
+    bf16x8 af[MT];
+    u32x2 t[2][3];
+    auto load_a = [&](int st, int m) __attribute__((always_inline)) {
+      af[m] = tr_read8(lds + a_off[m][0] + st * TW * RBD, lds + a_off[m][1] + st * TW * RBD);
+    };
+    auto load_t = [&](int buf, int st, int j) __attribute__((always_inline)) {
+      const char* p = lds + t_off[j] + st * rowstep[j];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        t[buf][i] = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, p + i * pixstep[j])));
+    };
+#pragma unroll
+    for (int m = 0; m < MT; ++m) load_a(0, m);
+    load_t(0, 0, 0);
+    static_for<KPG * UPW>([&](auto uc) __attribute__((always_inline)) {
+      constexpr int us = decltype(uc)::value;
+      constexpr int st = us / UPW, j = us % UPW, cur = us & 1;
+      constexpr bool more = us + 1 < KPG * UPW;
+      constexpr bool reload = (j == UPW - 1) && st + 1 < KPG;
+      if constexpr (more) load_t(cur ^ 1, (us + 1) / UPW, (us + 1) % UPW);
+      u32x4 win[3];
+      win[0] = u32x4{t[cur][0][0], t[cur][0][1], t[cur][1][0], t[cur][1][1]};
+      win[1] = u32x4{__builtin_amdgcn_alignbit(t[cur][0][1], t[cur][0][0], 16),
+                     __builtin_amdgcn_alignbit(t[cur][1][0], t[cur][0][1], 16),
+                     __builtin_amdgcn_alignbit(t[cur][1][1], t[cur][1][0], 16),
+                     __builtin_amdgcn_alignbit(t[cur][2][0], t[cur][1][1], 16)};
+      win[2] = u32x4{t[cur][0][1], t[cur][1][0], t[cur][1][1], t[cur][2][0]};
+      // (a unit past the wave's last one multiplies into accumulators nobody stores: every wave runs
+      // the same instruction stream, no branch around the reads in flight)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+          acc[j][m][kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], __builtin_bit_cast(bf16x8, win[kx]),
+                                                                  acc[j][m][kx], 0, 0, 0);
+        if constexpr (reload) load_a(st + 1, m);
+      }
+    });
+  };
+
+  auto tile_at = [&](int j) { return pos + j * nwg; };
+  if constexpr (S == 2) {
+    if (n > 0) issue_tile(tile_at(0), buf0);
+#pragma unroll 1
+    for (int j = 0; j < n; j += 2) {
+      __syncthreads();
+      if (j + 1 < n) issue_tile(tile_at(j + 1), buf1);
+      multiply(buf0);
+      if (j + 1 >= n) break;
+      __syncthreads();
+      if (j + 2 < n) issue_tile(tile_at(j + 2), buf0);
+      multiply(buf1);
+    }
+  } else {
+    auto sync_tile = [&](bool newer_in_flight) {
+      if (newer_in_flight) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    if (n > 0) issue_tile(tile_at(0), buf0);
+    if (n > 1) issue_tile(tile_at(1), buf1);
+#pragma unroll 1
+    for (int j = 0; j < n; j += 3) {
+      sync_tile(j + 1 < n);
+      if (j + 2 < n) issue_tile(tile_at(j + 2), buf2);
+      multiply(buf0);
+      if (j + 1 >= n) break;
+      sync_tile(j + 2 < n);
+      if (j + 3 < n) issue_tile(tile_at(j + 3), buf0);
+      multiply(buf1);
+      if (j + 2 >= n) break;
+      sync_tile(j + 3 < n);
+      if (j + 4 < n) issue_tile(tile_at(j + 4), buf1);
+      multiply(buf2);
+    }
+  }
+
+  // slab[pos][co][tap][ci]; C layout: col (ci) = lane&15, row (co) = 4*(lane>>4)+r
+  float* slab = a.slab + ((long)pos * NKG + kg) * a.Co_pad * 9 * a.Ci_pad;
+#pragma unroll
+  for (int j = 0; j < UPW; ++j) {
+    const int u = wu + WPG * j;
+    if (u >= NUNITS) continue;
+    const int slice = u / 3, ky = u - 3 * slice;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = m * 16 + 4 * g + r;
+          slab[((long)co * 9 + ky * 3 + kx) * a.Ci_pad + slice * 16 + li] = acc[j][m][kx][r];
+        }
+  }
+}
+
+
+// dw[co][ci][tap] (+)= sum_s slab[s][co][tap][ci] for MANY slabs of a small dw (the whole-pixel kernel
+// leaves one slab per workgroup): a workgroup owns 16 quads of four consecutive input channels and 16
+// slab lanes; lane j sums the slabs j, j+16, ... in order with four loads in flight, then the 16 lane sums
+// are added in lane order: the same bits every run, and a dependency chain of nslab/64 loads
+// instead of nslab/4.
+__global__ __launch_bounds__(256) void wgrad_reduce_many_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                                int nslab, int Co, int Ci, int Co_pad, int Ci_pad,
+                                                                int taps, int accumulate) {
+  __shared__ f32x4 part[16][16];
+  const int e = threadIdx.x & 15, j = threadIdx.x >> 4;
+  const int cq = Ci_pad / 4;
+  const long nquads = (long)Co * taps * cq;
+  const long idx = (long)blockIdx.x * 16 + e;
+  f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (idx < nquads) {
+    const float* p = slab + idx * 4;                       // [co][tap][ci] is the slab's own order
+    const long stride = (long)Co_pad * taps * Ci_pad;
+    int i = j;
+    for (; i + 48 < nslab; i += 64) {
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + i * stride);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (i + 16) * stride);
+      const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (i + 32) * stride);
+      const f32x4 v3 = *reinterpret_cast<const f32x4*>(p + (i + 48) * stride);
+      s = (((s + v0) + v1) + v2) + v3;
+    }
+    for (; i < nslab; i += 16) s += *reinterpret_cast<const f32x4*>(p + i * stride);
+  }
+  part[j][e] = s;
+  __syncthreads();
+  if (j == 0 && idx < nquads) {
+    f32x4 t = part[0][e];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += part[k][e];
+    const int ci = (int)(idx % cq) * 4;
+    const long ct = idx / cq;
+    const int tap = (int)(ct % taps), co = (int)(ct / taps);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (ci + k < Ci) {
+        float* d = dw + ((long)co * Ci + ci + k) * taps + tap;
+        *d = accumulate ? (*d + t[k]) : t[k];
+      }
+  }
+}
+
+struct PxPlan {
+  bool ok;
+  int ns1, ns2, nkg, tiles_x, tiles_y, ntiles, nwg, Ci_pad;
+};
+
+// The whole-pixel kernel takes 48 output channels and 48, 96 + 48 or 144 dense input channels.
+inline PxPlan plan_px(int B, int H, int W, int Ci, int Co, int ks, int dtype, int Ci1) {
+  PxPlan p;
+  p.ok = false;
+  if (dtype != UNETK_BF16 || ks != 3 || Co != 48) return p;
+  if (Ci1 == 0 && Ci == 48) { p.ns1 = 3; p.ns2 = 0; p.nkg = getenv("UNETK_PX_NKG1") ? 1 : 2; }
+  else if (Ci1 == 0 && Ci == 144) { p.ns1 = 9; p.ns2 = 0; p.nkg = 1; }
+  else if (Ci1 == 96 && Ci == 144) { p.ns1 = 6; p.ns2 = 3; p.nkg = 1; }
+  else return p;
+  p.tiles_x = cdiv(W, 32);
+  p.tiles_y = cdiv(H, 4);
+  p.ntiles = B * p.tiles_x * p.tiles_y;
+  if (p.ntiles < 256) return p;            // small images: the generic kernel's finer split fills the chip better
+  p.nwg = (p.ntiles / 8) & ~7;             // at least eight tiles per workgroup, one workgroup per CU at most
+  if (p.nwg > 256) p.nwg = 256;
+  p.Ci_pad = cdiv(Ci, 32) * 32;
+  p.ok = true;
+  return p;
+}
+inline int64_t px_workspace_bytes(int B, int H, int W, int Ci, int Co, int ks, int dtype) {
+  int64_t need = 0;
+  for (int c1 : {0, 96}) {
+    const PxPlan p = plan_px(B, H, W, Ci, Co, ks, dtype, c1);
+    if (p.ok && (int64_t)p.nwg * p.nkg * 48 * 9 * p.Ci_pad * 4 > need) need = (int64_t)p.nwg * p.nkg * 48 * 9 * p.Ci_pad * 4;
+  }
+  return need;
+}
+
 struct WgradPlan {
   int mt, tw, nwn, nwk, tpix, tr, tiles_x, tiles_y, ntiles, nsplit, Co_pad, Ci_pad;
 };
@@ -525,6 +845,7 @@ WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int dtype, int ks) {
       (Ci % 64 == 0 || (Ci > 256 && (Ci % 64) > 32) || (low_intensity && Ci > 32)))
     p.nwn = 4;
   if (ks == 1 && dtype == UNETK_BF16 && Ci >= 64) p.nwn = 1;   // plain GEMM: 4 channel slices per wave
+  if (ks == 3 && dtype == UNETK_BF16 && Ci % 64 == 0 && getenv("UNETK_WGRAD_NWN2") == nullptr) p.nwn = 4;
   if (ks == 1 && p.nwn == 1 && Co % 64 == 0) p.mt = 4;     // same for the sliced 1x1 form (64 x 64 outputs per workgroup)
   p.nwk = 8 / p.nwn;
   p.tpix = dtype == UNETK_BF16 ? 256 : 128;
@@ -580,7 +901,10 @@ int launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t stream) {
     return UNETK_OK;                                                                                   \
   }
   WG_CASE(2, 16, 2) WG_CASE(2, 32, 2) WG_CASE(3, 16, 2) WG_CASE(3, 32, 2) WG_CASE(4, 16, 2) WG_CASE(4, 32, 2)
-  if constexpr (sizeof(T) == 2 && KS == 1) {   // 64-channel chunks: bf16 1x1 only
+  if constexpr (sizeof(T) == 2 && KS == 3) {   // 64-channel chunks
+    WG_CASE(2, 32, 4) WG_CASE(3, 32, 4) WG_CASE(4, 32, 4) WG_CASE(3, 16, 4) WG_CASE(4, 16, 4)
+  }
+  if constexpr (sizeof(T) == 2 && KS == 1) {   // 64-channel chunks, sliced form: bf16 1x1 only
     WG_CASE(2, 16, 4) WG_CASE(2, 32, 4) WG_CASE(3, 16, 4) WG_CASE(3, 32, 4) WG_CASE(4, 16, 4) WG_CASE(4, 32, 4)
     {
       WG_CASE(2, 16, 1) WG_CASE(2, 32, 1) WG_CASE(3, 16, 1) WG_CASE(3, 32, 1) WG_CASE(4, 16, 1) WG_CASE(4, 32, 1)
@@ -598,7 +922,9 @@ extern "C" {
 int64_t unetk_conv_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Co, int ks, int dtype) {
   refold_1x1(B, H, W, ks);
   const WgradPlan p = plan_wgrad(B, H, W, Ci, Co, dtype, ks);
-  return (int64_t)p.nsplit * p.Co_pad * ks * ks * p.Ci_pad * 4;
+  const int64_t generic = (int64_t)p.nsplit * p.Co_pad * ks * ks * p.Ci_pad * 4;
+  const int64_t px = px_workspace_bytes(B, H, W, Ci, Co, ks, dtype);
+  return generic > px ? generic : px;
 }
 
 static int wgrad_impl(const void* in, int ldin, const void* dy, int lddy, float* dw, float* dbias, int B, int H, int W,
@@ -613,6 +939,33 @@ static int wgrad_impl(const void* in, int ldin, const void* dy, int lddy, float*
   UNETK_CHECK_ARG(((uintptr_t)in % 16) == 0 && ((uintptr_t)dy % 16) == 0, "conv_wgrad: misaligned pointer");
   UNETK_CHECK_ARG((int64_t)B * H * W * (ldin > lddy ? ldin : lddy) < (1LL << 31),
                   "conv_wgrad: tensors of 2^31 elements or more are not supported");
+  if (dbias == nullptr && getenv("UNETK_WGRAD_NO_PX") == nullptr) {
+    // full-resolution 48-channel layers with dense operands: every pixel streamed once by one workgroup
+    const PxPlan pp = plan_px(B, H, W, Ci, Co, ks, dtype, in2 != nullptr ? Ci1 : 0);
+    const bool dense = in2 != nullptr ? (ldin == Ci1 && ldin2 == Ci - Ci1 && ((uintptr_t)in2 % 16) == 0 &&
+                                         (int64_t)B * H * W * ldin2 < (1LL << 31))
+                                      : ldin == Ci;
+    if (pp.ok && dense) {
+      const int64_t need_px = (int64_t)pp.nwg * pp.nkg * 48 * 9 * pp.Ci_pad * 4;
+      UNETK_CHECK_ARG(workspace_bytes >= need_px, "conv_wgrad: workspace %lld < %lld bytes", (long long)workspace_bytes,
+                      (long long)need_px);
+      WgradArgs a;
+      a.in = in; a.in2 = in2; a.ldin2 = ldin2; a.Ci1 = Ci1; a.dy = dy; a.slab = (float*)workspace; a.bias_slab = nullptr;
+      a.ldin = ldin; a.lddy = lddy; a.B = B; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.Ci_pad = pp.Ci_pad; a.Co_pad = 48;
+      a.tiles_x = pp.tiles_x; a.tiles_y = pp.tiles_y; a.ntiles = pp.ntiles; a.nsplit = pp.nwg; a.gx = a.gy = 0;
+      if (getenv("UNETK_PX_DEBUG")) a.gx = atoi(getenv("UNETK_PX_DEBUG"));
+      if (pp.ns1 == 3 && pp.nkg == 2) hipLaunchKernelGGL((conv_wgrad_px_kernel<3, 0, 2>), dim3(pp.nwg), dim3(512), 0, stream, a);
+      else if (pp.ns1 == 3) hipLaunchKernelGGL((conv_wgrad_px_kernel<3, 0, 1>), dim3(pp.nwg), dim3(512), 0, stream, a);
+      else if (pp.ns1 == 9) hipLaunchKernelGGL((conv_wgrad_px_kernel<9, 0, 1>), dim3(pp.nwg), dim3(512), 0, stream, a);
+      else hipLaunchKernelGGL((conv_wgrad_px_kernel<6, 3, 1>), dim3(pp.nwg), dim3(512), 0, stream, a);
+      UNETK_CHECK_LAUNCH();
+      const long nblocks = cdiv((long)Co * 9 * (pp.Ci_pad / 4), 16);
+      hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3((unsigned)nblocks), dim3(256), 0, stream, a.slab, dw,
+                         pp.nwg * pp.nkg, Co, Ci, 48, pp.Ci_pad, 9, accumulate);
+      UNETK_CHECK_LAUNCH();
+      return UNETK_OK;
+    }
+  }
   refold_1x1(B, H, W, ks);
   const WgradPlan p = plan_wgrad(B, H, W, Ci, Co, dtype, ks);
   const int64_t main_bytes = (int64_t)p.nsplit * p.Co_pad * ks * ks * p.Ci_pad * 4;
