@@ -586,7 +586,6 @@ __global__ __launch_bounds__(512) void conv_wgrad_px_kernel(WgradArgs a) {
     }
   }
   auto issue_tile = [&](int tile, char* dbuf) {
-    if (a.gx & 2) return;
     const int tx = tile % a.tiles_x;
     const int t2 = tile / a.tiles_x;
     const int ty = t2 % a.tiles_y;
@@ -650,7 +649,6 @@ __global__ __launch_bounds__(512) void conv_wgrad_px_kernel(WgradArgs a) {
       }
 
   auto multiply = [&](const char* lds) {
-    if (a.gx & 1) return;
     bf16x8 af[MT];
     u32x2 t[2][3];
     auto load_a = [&](int st, int m) __attribute__((always_inline)) {
@@ -802,7 +800,7 @@ inline PxPlan plan_px(int B, int H, int W, int Ci, int Co, int ks, int dtype, in
   PxPlan p;
   p.ok = false;
   if (dtype != UNETK_BF16 || ks != 3 || Co != 48) return p;
-  if (Ci1 == 0 && Ci == 48) { p.ns1 = 3; p.ns2 = 0; p.nkg = getenv("UNETK_PX_NKG1") ? 1 : 2; }
+  if (Ci1 == 0 && Ci == 48) { p.ns1 = 3; p.ns2 = 0; p.nkg = 2; }
   else if (Ci1 == 0 && Ci == 144) { p.ns1 = 9; p.ns2 = 0; p.nkg = 1; }
   else if (Ci1 == 96 && Ci == 144) { p.ns1 = 6; p.ns2 = 3; p.nkg = 1; }
   else return p;
@@ -829,7 +827,7 @@ struct WgradPlan {
   int mt, tw, nwn, nwk, tpix, tr, tiles_x, tiles_y, ntiles, nsplit, Co_pad, Ci_pad;
 };
 
-WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int dtype, int ks) {
+WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int dtype, int ks, bool chunk64 = true) {
   WgradPlan p;
   p.mt = (Co % 48 == 0) ? 3 : ((Co % 64 == 0 || Co > 48) ? 4 : (Co > 32 ? 3 : 2));
   // 3x3: 64-channel row blocks where they divide Co: fewer passes over the input halo per output,
@@ -845,7 +843,8 @@ WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int dtype, int ks) {
       (Ci % 64 == 0 || (Ci > 256 && (Ci % 64) > 32) || (low_intensity && Ci > 32)))
     p.nwn = 4;
   if (ks == 1 && dtype == UNETK_BF16 && Ci >= 64) p.nwn = 1;   // plain GEMM: 4 channel slices per wave
-  if (ks == 3 && dtype == UNETK_BF16 && Ci % 64 == 0 && getenv("UNETK_WGRAD_NWN2") == nullptr) p.nwn = 4;
+  // pieces per MFMA (chunk64 = false: a two-operand input whose first part is not whole 64-channel chunks)
+  if (ks == 3 && dtype == UNETK_BF16 && Ci % 64 == 0 && chunk64) p.nwn = 4;
   if (ks == 1 && p.nwn == 1 && Co % 64 == 0) p.mt = 4;     // same for the sliced 1x1 form (64 x 64 outputs per workgroup)
   p.nwk = 8 / p.nwn;
   p.tpix = dtype == UNETK_BF16 ? 256 : 128;
@@ -921,10 +920,13 @@ extern "C" {
 
 int64_t unetk_conv_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Co, int ks, int dtype) {
   refold_1x1(B, H, W, ks);
-  const WgradPlan p = plan_wgrad(B, H, W, Ci, Co, dtype, ks);
-  const int64_t generic = (int64_t)p.nsplit * p.Co_pad * ks * ks * p.Ci_pad * 4;
-  const int64_t px = px_workspace_bytes(B, H, W, Ci, Co, ks, dtype);
-  return generic > px ? generic : px;
+  int64_t need = px_workspace_bytes(B, H, W, Ci, Co, ks, dtype);
+  for (int c64 = 0; c64 < 2; ++c64) {        // (which 3x3 form runs depends on the operands: room for either)
+    const WgradPlan p = plan_wgrad(B, H, W, Ci, Co, dtype, ks, c64 != 0);
+    const int64_t bytes = (int64_t)p.nsplit * p.Co_pad * ks * ks * p.Ci_pad * 4;
+    if (bytes > need) need = bytes;
+  }
+  return need;
 }
 
 static int wgrad_impl(const void* in, int ldin, const void* dy, int lddy, float* dw, float* dbias, int B, int H, int W,
@@ -953,9 +955,7 @@ static int wgrad_impl(const void* in, int ldin, const void* dy, int lddy, float*
       a.in = in; a.in2 = in2; a.ldin2 = ldin2; a.Ci1 = Ci1; a.dy = dy; a.slab = (float*)workspace; a.bias_slab = nullptr;
       a.ldin = ldin; a.lddy = lddy; a.B = B; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.Ci_pad = pp.Ci_pad; a.Co_pad = 48;
       a.tiles_x = pp.tiles_x; a.tiles_y = pp.tiles_y; a.ntiles = pp.ntiles; a.nsplit = pp.nwg; a.gx = a.gy = 0;
-      if (getenv("UNETK_PX_DEBUG")) a.gx = atoi(getenv("UNETK_PX_DEBUG"));
-      if (pp.ns1 == 3 && pp.nkg == 2) hipLaunchKernelGGL((conv_wgrad_px_kernel<3, 0, 2>), dim3(pp.nwg), dim3(512), 0, stream, a);
-      else if (pp.ns1 == 3) hipLaunchKernelGGL((conv_wgrad_px_kernel<3, 0, 1>), dim3(pp.nwg), dim3(512), 0, stream, a);
+      if (pp.ns1 == 3) hipLaunchKernelGGL((conv_wgrad_px_kernel<3, 0, 2>), dim3(pp.nwg), dim3(512), 0, stream, a);
       else if (pp.ns1 == 9) hipLaunchKernelGGL((conv_wgrad_px_kernel<9, 0, 1>), dim3(pp.nwg), dim3(512), 0, stream, a);
       else hipLaunchKernelGGL((conv_wgrad_px_kernel<6, 3, 1>), dim3(pp.nwg), dim3(512), 0, stream, a);
       UNETK_CHECK_LAUNCH();
@@ -967,7 +967,7 @@ static int wgrad_impl(const void* in, int ldin, const void* dy, int lddy, float*
     }
   }
   refold_1x1(B, H, W, ks);
-  const WgradPlan p = plan_wgrad(B, H, W, Ci, Co, dtype, ks);
+  const WgradPlan p = plan_wgrad(B, H, W, Ci, Co, dtype, ks, in2 == nullptr || Ci1 % 64 == 0);
   const int64_t main_bytes = (int64_t)p.nsplit * p.Co_pad * ks * ks * p.Ci_pad * 4;
   const int64_t need = main_bytes + (dbias ? (int64_t)p.nsplit * p.Co_pad * 4 : 0);
   UNETK_CHECK_ARG(workspace_bytes >= need, "conv_wgrad: workspace %lld < %lld bytes",
