@@ -85,16 +85,19 @@ def test_conv_fwd_dgrad_wgrad(dt, shape):
     assert rel(dw2.cpu(), 2 * wr.grad) < TOL[dt]
 
 
-@pytest.mark.parametrize("shape", [(1, 128, 256, 48, 0), (2, 66, 250, 48, 0), (1, 132, 256, 144, 0), (1, 128, 256, 96, 48),
-                                   (4, 47, 161, 96, 48)])
+@pytest.mark.parametrize("shape", [(1, 128, 256, 48, 0, 48), (2, 66, 250, 48, 0, 48), (1, 132, 256, 144, 0, 48),
+                                   (1, 128, 256, 96, 48, 48), (4, 47, 161, 96, 48, 48), (1, 128, 256, 96, 0, 96),
+                                   (2, 66, 250, 48, 0, 96), (1, 132, 256, 192, 96, 96), (1, 128, 256, 288, 0, 96),
+                                   (4, 47, 161, 192, 96, 96)])
 def test_wgrad_whole_pixel_kernel(shape):
-    """The full-resolution 48-output-channel weight gradient (dense bf16 operands, one workgroup streams every pixel
-    once) against autograd and against the generic kernel; ragged sizes, one and two operands, accumulate."""
+    """The weight gradient of the full- and half-resolution layers (48 / 96 output channels, dense bf16 operands staged
+    as whole pixels, no k-split) against autograd and against the generic kernel; ragged sizes, one and two operands,
+    accumulate."""
     import os
     from unet_amd import ops
     dt = torch.bfloat16
-    B, H, W, C1, C2 = shape
-    Ci, Co = C1 + C2, 48
+    B, H, W, C1, C2, Co = shape
+    Ci = C1 + C2
     x = rnd((B, Ci, H, W), 61, dt)
     gy = rnd((B, Co, H, W), 62, dt)
     wr = torch.zeros((Co, Ci, 3, 3), requires_grad=True)

@@ -42,6 +42,7 @@ struct WgradArgs {
   int Ci_pad, Co_pad;
   int tiles_x, tiles_y, ntiles, nsplit;
   int gx, gy;               // workgroups along Ci and Co
+  int px_ngrp1, px_ngrp2;   // whole-pixel kernel: column groups of input slices in `in` and in `in2`
 };
 
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
@@ -529,11 +530,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 //    streams one contiguous band of the image (DRAM pages and TLB entries are shared), and the tiles
 //    above and below one another, which share two halo rows, run at the same time on one XCD (tile ids a
 //    multiple of 8 apart when the image is 256 wide) and share its L2.
-template <int NS1, int NS2, int NKG>
+// With 96 output channels (NCO = 2: the half-resolution layers) dw no longer fits one workgroup: COLUMNS of
+// workgroups = (48-channel half of the output) x (group of NS1 input slices of one operand) walk the same
+// tile lists; a column stages whole dy pixels (192 bytes) and the pixels of its input group (whole when the
+// group is the operand's full width, runs of NS1 * 32 bytes otherwise), and the columns of one tile list
+// get workgroup ids a multiple of 8 apart: one XCD, one L2.
+template <int NS1, int NS2, int NKG, int NCO = 1>
 __global__ __launch_bounds__(512) void conv_wgrad_px_kernel(WgradArgs a) {
   using T = bf16;
   constexpr int MT = 3, TW = 32, TR = 4, TPIX = TW * TR, HW_ = TW + 2, HH_ = TR + 2, HPIX = HW_ * HH_;
-  constexpr int RBD = MT * 32;                         // dy row bytes = the whole pixel
+  constexpr int RBD = NCO * MT * 32;                   // dy row bytes = the whole pixel
+  static_assert(NCO == 1 || NS2 == 0, "columns take their slices from one operand");
   constexpr int P1 = NS1 * 32, P2 = NS2 * 32;          // pixel pitch of the two input images
   constexpr int DINSTR = TPIX * RBD / 1024;
   constexpr int H1INSTR = (HPIX * P1 + 1023) / 1024, H2INSTR = (HPIX * P2 + 1023) / 1024;
@@ -557,8 +564,19 @@ __global__ __launch_bounds__(512) void conv_wgrad_px_kernel(WgradArgs a) {
   const T* in2 = reinterpret_cast<const T*>(a.in2);
   const T* zero = reinterpret_cast<const T*>(wgrad_zero_page);
 
-  const int nwg = gridDim.x;
-  const int pos = blockIdx.x;
+  // column (see above) and tile list of this workgroup
+  const int ncol = NCO * (a.px_ngrp1 + a.px_ngrp2);
+  const int nwg = gridDim.x / ncol;
+  const int col = ncol > 1 ? (blockIdx.x >> 3) % ncol : 0;
+  const int pos = ncol > 1 ? ((blockIdx.x >> 3) / ncol) * 8 + (blockIdx.x & 7) : blockIdx.x;
+  const int half = col % NCO, grp = col / NCO;
+  int ld1 = a.ldin, coff = grp * NS1 * 16, ci_base = coff;
+  if (NS2 == 0 && grp >= a.px_ngrp1) {            // this column's slices lie in the second operand
+    in1 = in2;
+    ld1 = a.ldin2;
+    coff = (grp - a.px_ngrp1) * NS1 * 16;
+    ci_base = a.Ci1 + coff;
+  }
   const int n = pos < a.ntiles ? (a.ntiles - pos + nwg - 1) / nwg : 0;      // tiles of this workgroup
 
   // ---- DMA tables: piece i = wave + 8k covers bytes [1024 i, 1024 i + 1024) of the stage (dy image, then
@@ -581,7 +599,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_px_kernel(WgradArgs a) {
       const int pitch = second ? P2 : P1;
       const int hp = o / pitch, byte = o - hp * pitch;
       const int hy = hp / HW_, hx = hp - hy * HW_;
-      p_off[k] = (hy * a.W + hx) * (second ? a.ldin2 : a.ldin) + (byte >> 1);
+      p_off[k] = (hy * a.W + hx) * (second ? a.ldin2 : ld1) + (second ? 0 : coff) + (byte >> 1);
       p_yx[k] = hp < HPIX ? ((hy << 16) | hx) : (0x7fff << 16);
     }
   }
@@ -592,7 +610,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_px_kernel(WgradArgs a) {
     const int b = t2 / a.tiles_y;
     const int y0 = ty * TR, x0 = tx * TW;
     const int d0 = ((b * a.H + y0) * a.W + x0) * a.lddy;
-    const int h1 = ((b * a.H + y0 - 1) * a.W + x0 - 1) * a.ldin;
+    const int h1 = ((b * a.H + y0 - 1) * a.W + x0 - 1) * ld1;
     const int h2 = NS2 > 0 ? ((b * a.H + y0 - 1) * a.W + x0 - 1) * a.ldin2 : 0;
 #pragma unroll
     for (int k = 0; k < NPW; ++k) {
@@ -618,7 +636,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_px_kernel(WgradArgs a) {
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int h = 0; h < 2; ++h)
-      a_off[m][h] = ((wave / WPG) * KPG * TW + 8 * g + q + 4 * h) * RBD + (2 * m + (p4 >> 1)) * 16 + (p4 & 1) * 8;
+      a_off[m][h] = ((wave / WPG) * KPG * TW + 8 * g + q + 4 * h) * RBD + half * (MT * 32) + (2 * m + (p4 >> 1)) * 16 +
+                    (p4 & 1) * 8;
   int t_off[UPW], rowstep[UPW], pixstep[UPW];
   bool uvalid[UPW];
   const int kg = wave / WPG, wu = wave % WPG;
@@ -686,6 +705,20 @@ __global__ __launch_bounds__(512) void conv_wgrad_px_kernel(WgradArgs a) {
                                                                   acc[j][m][kx], 0, 0, 0);
         if constexpr (reload) load_a(st + 1, m);
       }
+      // issue order (as in the generic kernel): first MFMA, the next unit's window reads, the rest of the row
+      // block, its dy reload, the next row block ...: no MFMA waits for a read issued in its own unit-step
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if constexpr (more) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      if constexpr (reload) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        static_for<MT - 1>([&](auto) __attribute__((always_inline)) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        });
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, 3 * MT - 1, 0);
+      }
     });
   };
 
@@ -738,8 +771,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_px_kernel(WgradArgs a) {
       for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int co = m * 16 + 4 * g + r;
-          slab[((long)co * 9 + ky * 3 + kx) * a.Ci_pad + slice * 16 + li] = acc[j][m][kx][r];
+          const int co = half * (MT * 16) + m * 16 + 4 * g + r;
+          slab[((long)co * 9 + ky * 3 + kx) * a.Ci_pad + ci_base + slice * 16 + li] = acc[j][m][kx][r];
         }
   }
 }
@@ -792,33 +825,48 @@ __global__ __launch_bounds__(256) void wgrad_reduce_many_kernel(const float* __r
 
 struct PxPlan {
   bool ok;
-  int ns1, ns2, nkg, tiles_x, tiles_y, ntiles, nwg, Ci_pad;
+  int ns1, ns2, nkg, nco, ngrp1, ngrp2, ncol, tiles_x, tiles_y, ntiles, nwg, Ci_pad;
 };
 
-// The whole-pixel kernel takes 48 output channels and 48, 96 + 48 or 144 dense input channels.
+// The whole-pixel kernel takes 48 output channels and 48, 96 + 48 or 144 input channels in one workgroup, or 96
+// output channels and 48, 96, 192 + 96 or 288 input channels in columns of workgroups.
 inline PxPlan plan_px(int B, int H, int W, int Ci, int Co, int ks, int dtype, int Ci1) {
   PxPlan p;
   p.ok = false;
-  if (dtype != UNETK_BF16 || ks != 3 || Co != 48) return p;
-  if (Ci1 == 0 && Ci == 48) { p.ns1 = 3; p.ns2 = 0; p.nkg = 2; }
-  else if (Ci1 == 0 && Ci == 144) { p.ns1 = 9; p.ns2 = 0; p.nkg = 1; }
-  else if (Ci1 == 96 && Ci == 144) { p.ns1 = 6; p.ns2 = 3; p.nkg = 1; }
-  else return p;
+  p.nco = 1; p.ngrp1 = 1; p.ngrp2 = 0; p.ns2 = 0; p.nkg = 1;
+  if (dtype != UNETK_BF16 || ks != 3) return p;
+  if (Co == 48) {
+    if (Ci1 == 0 && Ci == 48) { p.ns1 = 3; p.nkg = 2; }
+    else if (Ci1 == 0 && Ci == 144) { p.ns1 = 9; }
+    else if (Ci1 == 96 && Ci == 144) { p.ns1 = 6; p.ns2 = 3; }
+    else return p;
+  } else if (Co == 96 && getenv("UNETK_WGRAD_NO_PX96") == nullptr) {
+    p.nco = 2;
+    if (Ci1 == 0 && Ci == 48) { p.ns1 = 3; p.nkg = 2; }
+    else if (Ci1 == 0 && (Ci == 96 || Ci == 288)) { p.ns1 = 6; p.ngrp1 = Ci / 96; }
+    else if (Ci1 == 192 && Ci == 288) { p.ns1 = 6; p.ngrp1 = 2; p.ngrp2 = 1; }
+    else return p;
+  } else {
+    return p;
+  }
+  p.ncol = p.nco * (p.ngrp1 + p.ngrp2);
   p.tiles_x = cdiv(W, 32);
   p.tiles_y = cdiv(H, 4);
   p.ntiles = B * p.tiles_x * p.tiles_y;
   if (p.ntiles < 256) return p;            // small images: the generic kernel's finer split fills the chip better
-  p.nwg = (p.ntiles / 8) & ~7;             // at least eight tiles per workgroup, one workgroup per CU at most
-  if (p.nwg > 256) p.nwg = 256;
+  p.nwg = (p.ntiles / 8) & ~7;             // tile lists: at least eight tiles each, one workgroup per CU at most
+  const int most = (256 / p.ncol) & ~7;
+  if (p.nwg > most) p.nwg = most;
   p.Ci_pad = cdiv(Ci, 32) * 32;
   p.ok = true;
   return p;
 }
 inline int64_t px_workspace_bytes(int B, int H, int W, int Ci, int Co, int ks, int dtype) {
   int64_t need = 0;
-  for (int c1 : {0, 96}) {
+  for (int c1 : {0, 96, 192}) {
     const PxPlan p = plan_px(B, H, W, Ci, Co, ks, dtype, c1);
-    if (p.ok && (int64_t)p.nwg * p.nkg * 48 * 9 * p.Ci_pad * 4 > need) need = (int64_t)p.nwg * p.nkg * 48 * 9 * p.Ci_pad * 4;
+    const int64_t bytes = (int64_t)p.nwg * p.nkg * 48 * p.nco * 9 * p.Ci_pad * 4;
+    if (p.ok && bytes > need) need = bytes;
   }
   return need;
 }
@@ -948,20 +996,25 @@ static int wgrad_impl(const void* in, int ldin, const void* dy, int lddy, float*
                                          (int64_t)B * H * W * ldin2 < (1LL << 31))
                                       : ldin == Ci;
     if (pp.ok && dense) {
-      const int64_t need_px = (int64_t)pp.nwg * pp.nkg * 48 * 9 * pp.Ci_pad * 4;
+      const int co_pad = 48 * pp.nco;
+      const int64_t need_px = (int64_t)pp.nwg * pp.nkg * co_pad * 9 * pp.Ci_pad * 4;
       UNETK_CHECK_ARG(workspace_bytes >= need_px, "conv_wgrad: workspace %lld < %lld bytes", (long long)workspace_bytes,
                       (long long)need_px);
       WgradArgs a;
       a.in = in; a.in2 = in2; a.ldin2 = ldin2; a.Ci1 = Ci1; a.dy = dy; a.slab = (float*)workspace; a.bias_slab = nullptr;
-      a.ldin = ldin; a.lddy = lddy; a.B = B; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.Ci_pad = pp.Ci_pad; a.Co_pad = 48;
+      a.ldin = ldin; a.lddy = lddy; a.B = B; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.Ci_pad = pp.Ci_pad; a.Co_pad = co_pad;
       a.tiles_x = pp.tiles_x; a.tiles_y = pp.tiles_y; a.ntiles = pp.ntiles; a.nsplit = pp.nwg; a.gx = a.gy = 0;
-      if (pp.ns1 == 3) hipLaunchKernelGGL((conv_wgrad_px_kernel<3, 0, 2>), dim3(pp.nwg), dim3(512), 0, stream, a);
-      else if (pp.ns1 == 9) hipLaunchKernelGGL((conv_wgrad_px_kernel<9, 0, 1>), dim3(pp.nwg), dim3(512), 0, stream, a);
-      else hipLaunchKernelGGL((conv_wgrad_px_kernel<6, 3, 1>), dim3(pp.nwg), dim3(512), 0, stream, a);
+      a.px_ngrp1 = pp.ngrp1; a.px_ngrp2 = pp.ngrp2;
+      const dim3 grid((unsigned)(pp.nwg * pp.ncol));
+      if (pp.nco == 2 && pp.ns1 == 3) hipLaunchKernelGGL((conv_wgrad_px_kernel<3, 0, 2, 2>), grid, dim3(512), 0, stream, a);
+      else if (pp.nco == 2) hipLaunchKernelGGL((conv_wgrad_px_kernel<6, 0, 1, 2>), grid, dim3(512), 0, stream, a);
+      else if (pp.ns1 == 3) hipLaunchKernelGGL((conv_wgrad_px_kernel<3, 0, 2>), grid, dim3(512), 0, stream, a);
+      else if (pp.ns1 == 9) hipLaunchKernelGGL((conv_wgrad_px_kernel<9, 0, 1>), grid, dim3(512), 0, stream, a);
+      else hipLaunchKernelGGL((conv_wgrad_px_kernel<6, 3, 1>), grid, dim3(512), 0, stream, a);
       UNETK_CHECK_LAUNCH();
       const long nblocks = cdiv((long)Co * 9 * (pp.Ci_pad / 4), 16);
       hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3((unsigned)nblocks), dim3(256), 0, stream, a.slab, dw,
-                         pp.nwg * pp.nkg, Co, Ci, 48, pp.Ci_pad, 9, accumulate);
+                         pp.nwg * pp.nkg, Co, Ci, co_pad, pp.Ci_pad, 9, accumulate);
       UNETK_CHECK_LAUNCH();
       return UNETK_OK;
     }
