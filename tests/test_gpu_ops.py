@@ -314,10 +314,12 @@ def test_conv_fused_pool_and_head(dt, shape):
 
 
 @pytest.mark.parametrize("ntok,Ci,Co", [(64 * 64 * 4, 96, 288), (4096, 384, 96), (1000, 192, 192), (8 * 8 * 3, 768, 3072),
-                                        (256, 32, 48)])
+                                        (256, 32, 48), (5000, 96, 96), (4133, 96, 384), (9001, 384, 96), (4096, 192, 576),
+                                        (4100, 192, 192), (3001, 192, 768), (2100, 768, 192), (32 * 32 * 8, 192, 768)])
 def test_linear_wgrad_with_bias(ntok, Ci, Co):
     """nn.Linear backward over tokens: dw = dy^T x and db = sum dy from one pass (bf16), against fp64 sums of the
-    same bf16-rounded operands."""
+    same bf16-rounded operands (the narrow shapes over at least 2048-4096 tokens take the whole-row kernel: ragged
+    last tiles, every column split)."""
     from unet_amd import ops
     g = torch.Generator(device="cuda").manual_seed(ntok + Ci)
     x = torch.randn((ntok, Ci), device="cuda", generator=g).to(torch.bfloat16)

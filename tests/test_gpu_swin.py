@@ -194,7 +194,9 @@ def test_token_weight_gradient_gemm(shape):
     xw = torch.zeros((B, H, Wd, K + 16), dtype=dt, device="cuda")
     xw[..., 8:8 + K] = xd
     dw3, _ = ops.token_wgrad(xw[..., 8:8 + K], dyd, K, N)
-    assert torch.equal(dw3, dw)
+    # (the same bits from the same kernel; the narrow layers over many tokens take the whole-row kernel only with
+    # dense operands, and the tile kernel sums in another order)
+    assert torch.equal(dw3, dw) or (B * H * Wd >= 2048 and rel(dw3, dw) < 1e-6)
 
 
 def build(dt):

@@ -19,6 +19,11 @@
 #include "common.h"
 #include <cstdlib>
 
+// the whole-row kernel of the narrow token linears (gemm.hip)
+int64_t lin_wgrad_rows_workspace(int64_t M, int K, int N);
+int lin_wgrad_rows_try(const void* x, int ldx, const void* dy, int lddy, float* dw, float* db, int64_t M, int K, int N,
+                       void* ws, int64_t ws_bytes, int accumulate, hipStream_t stream, int* rc);
+
 namespace {
 
 // page of zeros that out-of-image pixels and channel padding load
@@ -1071,7 +1076,9 @@ int64_t unetk_linear_wgrad_workspace_bytes(int64_t npix, int Ci, int Co, int dty
   if (npix >= (1LL << 31)) return -1;
   refold_1x1(B, H, W, 1);
   const WgradPlan p = plan_wgrad(B, H, W, Ci, Co, dtype, 1);
-  return (int64_t)p.nsplit * p.Co_pad * p.Ci_pad * 4 + (int64_t)p.nsplit * p.Co_pad * 4;
+  const int64_t generic = (int64_t)p.nsplit * p.Co_pad * p.Ci_pad * 4 + (int64_t)p.nsplit * p.Co_pad * 4;
+  const int64_t rows = dtype == UNETK_BF16 ? lin_wgrad_rows_workspace(npix, Ci, Co) : 0;
+  return generic > rows ? generic : rows;
 }
 
 int unetk_linear_wgrad(const void* in, int ldin, const void* dy, int lddy, float* dw, float* dbias, int64_t npix,
@@ -1080,6 +1087,11 @@ int unetk_linear_wgrad(const void* in, int ldin, const void* dy, int lddy, float
   UNETK_CHECK_ARG(dbias != nullptr, "linear_wgrad: null bias gradient (use conv_wgrad)");
   UNETK_CHECK_ARG(dtype == UNETK_BF16, "linear_wgrad: bfloat16 only (the bias sums ride on the bf16 MFMA path)");
   UNETK_CHECK_ARG(npix > 0 && npix < (1LL << 31), "linear_wgrad: bad token count");
+  UNETK_CHECK_ARG(in && dy && dw && workspace && ((uintptr_t)in % 16) == 0 && ((uintptr_t)dy % 16) == 0 &&
+                  ((uintptr_t)dw % 16) == 0, "linear_wgrad: null or misaligned pointer");
+  int rc = UNETK_OK;
+  if (lin_wgrad_rows_try(in, ldin, dy, lddy, dw, dbias, npix, Ci, Co, workspace, workspace_bytes, accumulate, stream, &rc))
+    return rc;
   return wgrad_impl(in, ldin, dy, lddy, dw, dbias, 1, 1, (int)npix, Ci, Co, 1, dtype, workspace, workspace_bytes,
                     accumulate, stream);
 }

@@ -29,6 +29,7 @@
 // [N/BN][K/32][BN][32]: a stage's weight slab is one contiguous run.
 #include "common.h"
 #include "mma.h"
+#include <cstdlib>
 
 namespace {
 
@@ -464,6 +465,59 @@ __global__ __launch_bounds__(256) void lin_wgrad_reduce_kernel(const float* __re
   }
 }
 
+
+// The same sum for MANY slabs of a small dw (one slab per workgroup of the whole-row kernel): 16 slab lanes
+// per quad of dw (or per bias element), each summing its slabs j, j+16, ... in order with four loads in
+// flight, the 16 lane sums added in lane order: a dependency chain of nsplit/64 loads instead of nsplit/16,
+// the same bits every run.
+__global__ __launch_bounds__(256) void lin_wgrad_reduce16_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                                 const float* __restrict__ bias_slab,
+                                                                 float* __restrict__ db, int nsplit, int N, int K,
+                                                                 int accumulate, int nmain_blocks) {
+  __shared__ f32x4 part[16][16];
+  const int e = threadIdx.x & 15, j = threadIdx.x >> 4;
+  if ((int)blockIdx.x >= nmain_blocks) {
+    const int n = (blockIdx.x - nmain_blocks) * 16 + e;
+    float sum = 0.f;
+    if (n < N)
+      for (int i = j; i < nsplit; i += 16) sum += bias_slab[(long)i * N + n];
+    part[j][e] = f32x4{sum, 0.f, 0.f, 0.f};
+    __syncthreads();
+    if (j == 0 && n < N) {
+      float t = part[0][e][0];
+#pragma unroll
+      for (int k = 1; k < 16; ++k) t += part[k][e][0];
+      db[n] = accumulate ? db[n] + t : t;
+    }
+    return;
+  }
+  const long nquads = (long)N * (K / 4);
+  const long idx = (long)blockIdx.x * 16 + e;
+  f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (idx < nquads) {
+    const float* p = slab + idx * 4;
+    const long stride = (long)N * K;
+    int i = j;
+    for (; i + 48 < nsplit; i += 64) {
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + i * stride);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (i + 16) * stride);
+      const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (i + 32) * stride);
+      const f32x4 v3 = *reinterpret_cast<const f32x4*>(p + (i + 48) * stride);
+      sum = (((sum + v0) + v1) + v2) + v3;
+    }
+    for (; i < nsplit; i += 16) sum += *reinterpret_cast<const f32x4*>(p + i * stride);
+  }
+  part[j][e] = sum;
+  __syncthreads();
+  if (j == 0 && idx < nquads) {
+    f32x4 t = part[0][e];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += part[k][e];
+    f32x4* d = reinterpret_cast<f32x4*>(dw + idx * 4);
+    *d = accumulate ? (*d + t) : t;
+  }
+}
+
 struct WgPlan {
   int N_pad, K_pad, gn, gk, nsplit, chunk;
 };
@@ -496,6 +550,259 @@ inline WgPlan plan_lin_wgrad(long M, int K, int N) {
   return p;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Whole-row weight gradient of the NARROW token linears (stages 0 and 1 of the Swin encoder: 96 ... 768
+// channels over 65 536 ... 262 144 tokens): dw is small and the reduction long, so the product is bound by
+// the bytes of x and dy.  A workgroup of eight waves owns a COLUMN of dw - all of it when it fits the
+// registers (<= 36 accumulator tiles per wave), else a range of 16-row / 16-column tiles - and streams its
+// tokens exactly once: token rows are staged whole (the LDS images of dy and x are byte-for-byte copies of
+// TT consecutive token rows, so every DMA piece reads 1 KiB of consecutive memory), waves split the
+// output rows (NTW 16-row tiles each, all KTC column tiles), nothing is summed through LDS, and each
+// workgroup leaves one fp32 slab for lin_wgrad_reduce_kernel.  Both fragments are read with the transposing
+// ds_read_b64_tr_b16; the 32-byte unit of a tile inside the largest power-of-two block that divides the row
+// pitch is XORed with token bits (on the DMA source and on the read address alike: a permutation inside a
+// piece costs nothing) so that the eight token rows of a read fall on eight different bank groups.
+struct RowsArgs {
+  const bf16* x;
+  const bf16* dy;
+  float* slab;        // [nwg][N][K]
+  float* bias_slab;   // [nwg][N]
+  int M, nwg, ntile;
+};
+
+template <int K, int N> struct RowsShape {
+  static constexpr int NTIL = N / 16, KTIL = K / 16;
+  static constexpr int CK = KTIL > 24 ? KTIL / 12 : 1;                 // columns along K
+  static constexpr int KTC = KTIL / CK;                                // k-tiles per column
+  static constexpr int NTW_MAX = (36 / KTC) < 3 ? (36 / KTC) : 3;
+  static constexpr int CN = (NTIL + 8 * NTW_MAX - 1) / (8 * NTW_MAX);  // columns along N
+  static constexpr int NTC = NTIL / CN;                                // n-tiles per column
+  static constexpr int NTW = (NTC + 7) / 8;                            // n-tiles per wave
+  static constexpr int NCOL = CN * CK;
+  static constexpr int TT = (2 * 64 * (N + K) * 2 <= 150 * 1024) ? 64 : 32;   // tokens per stage
+  static constexpr int DBYTES = TT * N * 2, XBYTES = TT * K * 2, STAGE = DBYTES + XBYTES;
+  static constexpr int S = (3 * STAGE <= 150 * 1024) ? 3 : 2;
+  static_assert(N % 16 == 0 && K % 16 == 0 && NTIL % CN == 0 && KTIL % CK == 0 && STAGE % 1024 == 0 && DBYTES % 1024 == 0,
+                "shape");
+};
+
+// swizzle block (bytes) of a row pitch and the XOR key of a token row
+__host__ __device__ constexpr int rows_block(int pitch) { return pitch % 256 == 0 ? 256 : (pitch % 128 == 0 ? 128 : 64); }
+template <int BS> __device__ __forceinline__ int rows_key(int t) {
+  if (BS == 256) return (t & 3) | (((t >> 3) & 1) << 2);
+  if (BS == 128) return ((t >> 1) & 1) | (((t >> 3) & 1) << 1);
+  return (t >> 3) & 1;
+}
+
+template <int K, int N>
+__global__ __launch_bounds__(512) void lin_wgrad_rows_kernel(RowsArgs a) {
+  using SH = RowsShape<K, N>;
+  constexpr int PD = N * 2, PX = K * 2;                      // row pitches
+  constexpr int BD = rows_block(PD), BX = rows_block(PX);
+  constexpr int TT = SH::TT, S = SH::S, STAGE = SH::STAGE, DBYTES = SH::DBYTES;
+  constexpr int NINSTR = STAGE / 1024, NPW = (NINSTR + 7) / 8, DINSTR = DBYTES / 1024;
+  constexpr int NTW = SH::NTW, KTC = SH::KTC, KB = KTC > 12 ? 12 : KTC;     // k-tiles per register batch
+  static_assert(KTC % KB == 0 && 2 * NPW < 64, "batches");
+  __shared__ __attribute__((aligned(1024))) char buf0[STAGE];
+  __shared__ __attribute__((aligned(1024))) char buf1[STAGE];
+  __shared__ __attribute__((aligned(1024))) char buf2[S == 3 ? STAGE : 1024];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bf16* zero = reinterpret_cast<const bf16*>(gemm_zero_page);
+  // column and token-tile list of this workgroup: the columns of one list get ids a multiple of 8 apart (one XCD)
+  constexpr int NCOL = SH::NCOL;
+  const int col = NCOL > 1 ? (blockIdx.x >> 3) % NCOL : 0;
+  const int pos = NCOL > 1 ? ((blockIdx.x >> 3) / NCOL) * 8 + (blockIdx.x & 7) : blockIdx.x;
+  const int cn = col % SH::CN, ck = col / SH::CN;
+  const int n = pos < a.ntile ? (a.ntile - pos + a.nwg - 1) / a.nwg : 0;
+
+  // ---- DMA table: piece i = wave + 8k is bytes [1024 i, 1024 i + 1024) of the stage; the source is the same
+  // byte of the token block with the swizzled 32-byte unit; rows past M read zeros
+  int p_off[NPW], p_tok[NPW];
+#pragma unroll
+  for (int k = 0; k < NPW; ++k) {
+    int i = wave + 8 * k;
+    if (i >= NINSTR) i = NINSTR - 1;
+    const bool isd = i < DINSTR;
+    const int o = (isd ? i : i - DINSTR) * 1024 + lane * 16;
+    const int pitch = isd ? PD : PX, bs = isd ? BD : BX;
+    const int t = o / pitch, cb = o - t * pitch;
+    const int key = isd ? rows_key<BD>(t) : rows_key<BX>(t);
+    const int cbs = (cb & ~(bs - 1)) | ((cb & (bs - 1)) ^ (key * 32));
+    p_off[k] = (t * pitch + cbs) >> 1;
+    p_tok[k] = t;
+  }
+  auto issue_tile = [&](int tile, char* dst) {
+    const int t0 = tile * TT;
+    const bf16* dbase = a.dy + (long)t0 * N;
+    const bf16* xbase = a.x + (long)t0 * K;
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) {
+      int i = wave + 8 * k;
+      if (i >= NINSTR) i = NINSTR - 1;
+      const bool ok = t0 + p_tok[k] < a.M;
+      const bf16* src = ok ? (i < DINSTR ? dbase : xbase) + p_off[k] : zero;
+      glds16g(src, dst + i * 1024);
+    }
+  };
+
+  // ---- fragment addresses: lane (g, q, p4) reads tokens 8g + q (+4) at the 8 bytes (p4) of a 16-channel tile
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, p4 = li & 3;
+  const int tl = 8 * g + q;
+  const int keyd = rows_key<BD>(tl), keyx = rows_key<BX>(tl);
+  constexpr int UD = BD / 32, UX = BX / 32;
+  const int nt0 = cn * SH::NTC + wave * NTW;                 // this wave's first n-tile (tiles past the column: idle)
+  const bool active = wave * NTW < SH::NTC;
+  int a_off[NTW], b_off[KTC];
+#pragma unroll
+  for (int m = 0; m < NTW; ++m) {
+    int nt = nt0 + m;
+    if (nt >= (cn + 1) * SH::NTC) nt = (cn + 1) * SH::NTC - 1;
+    const int nts = (nt & ~(UD - 1)) | ((nt ^ keyd) & (UD - 1));
+    a_off[m] = tl * PD + nts * 32 + (p4 >> 1) * 16 + (p4 & 1) * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < KTC; ++j) {
+    const int kt = ck * KTC + j;
+    const int kts = (kt & ~(UX - 1)) | ((kt ^ keyx) & (UX - 1));
+    b_off[j] = DBYTES + tl * PX + kts * 32 + (p4 >> 1) * 16 + (p4 & 1) * 8;
+  }
+
+  f32x4 acc[NTW][KTC], accb[NTW];
+#pragma unroll
+  for (int m = 0; m < NTW; ++m) {
+    accb[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("" : "+v"(accb[m]));
+#pragma unroll
+    for (int j = 0; j < KTC; ++j) {
+      acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      asm volatile("" : "+v"(acc[m][j]));      // (opaque zeros: see conv_wgrad_kernel)
+    }
+  }
+  const bool want_bias = a.bias_slab != nullptr && ck == 0;
+
+  auto tr8 = [&](const char* p, int pitch) __attribute__((always_inline)) {
+    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, p));
+    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, p + 4 * pitch));
+    typedef __attribute__((ext_vector_type(8))) short short8v;
+    return __builtin_bit_cast(bf16x8, short8v{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+  };
+  auto multiply = [&](const char* lds) {
+    if (!active) return;
+#pragma unroll
+    for (int ks = 0; ks < TT / 32; ++ks) {
+      bf16x8 af[NTW];
+#pragma unroll
+      for (int m = 0; m < NTW; ++m) af[m] = tr8(lds + a_off[m] + ks * 32 * PD, PD);
+      if (want_bias) {      // (uniform) dy^T times a matrix of ones: every column = the sum over the step's tokens
+        const u32x4 ones = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+#pragma unroll
+        for (int m = 0; m < NTW; ++m)
+          accb[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], __builtin_bit_cast(bf16x8, ones), accb[m], 0, 0, 0);
+      }
+#pragma unroll
+      for (int jb = 0; jb < KTC; jb += KB) {
+        bf16x8 bfr[KB];
+#pragma unroll
+        for (int j = 0; j < KB; ++j) bfr[j] = tr8(lds + b_off[jb + j] + ks * 32 * PX, PX);
+#pragma unroll
+        for (int j = 0; j < KB; ++j)
+#pragma unroll
+          for (int m = 0; m < NTW; ++m)
+            acc[m][jb + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr[j], acc[m][jb + j], 0, 0, 0);
+      }
+    }
+  };
+
+  auto tile_at = [&](int j) { return pos + j * a.nwg; };
+  if constexpr (S == 2) {
+    if (n > 0) issue_tile(tile_at(0), buf0);
+#pragma unroll 1
+    for (int j = 0; j < n; j += 2) {
+      __syncthreads();
+      if (j + 1 < n) issue_tile(tile_at(j + 1), buf1);
+      multiply(buf0);
+      if (j + 1 >= n) break;
+      __syncthreads();
+      if (j + 2 < n) issue_tile(tile_at(j + 2), buf0);
+      multiply(buf1);
+    }
+  } else {
+    auto sync_tile = [&](bool newer_in_flight) {
+      if (newer_in_flight) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    if (n > 0) issue_tile(tile_at(0), buf0);
+    if (n > 1) issue_tile(tile_at(1), buf1);
+#pragma unroll 1
+    for (int j = 0; j < n; j += 3) {
+      sync_tile(j + 1 < n);
+      if (j + 2 < n) issue_tile(tile_at(j + 2), buf2);
+      multiply(buf0);
+      if (j + 1 >= n) break;
+      sync_tile(j + 2 < n);
+      if (j + 3 < n) issue_tile(tile_at(j + 3), buf0);
+      multiply(buf1);
+      if (j + 2 >= n) break;
+      sync_tile(j + 3 < n);
+      if (j + 4 < n) issue_tile(tile_at(j + 4), buf1);
+      multiply(buf2);
+    }
+  }
+
+  // slab[pos][n][k]; C layout: column (k) = lane&15, row (n) = 4*(lane>>4) + r
+  if (!active) return;
+  float* slab = a.slab + (long)pos * N * K;
+#pragma unroll
+  for (int m = 0; m < NTW; ++m) {
+    const int nt = nt0 + m;
+    if (nt >= (cn + 1) * SH::NTC) continue;
+#pragma unroll
+    for (int j = 0; j < KTC; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        slab[(long)(nt * 16 + 4 * g + r) * K + (ck * KTC + j) * 16 + li] = acc[m][j][r];
+    if (want_bias && li == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a.bias_slab[(long)pos * N + nt * 16 + 4 * g + r] = accb[m][r];
+    }
+  }
+}
+
+template <int K, int N> int rows_nwg(long M) {
+  using SH = RowsShape<K, N>;
+  const long ntile = (M + SH::TT - 1) / SH::TT;
+  int nwg = (int)((ntile / 8) & ~7L);           // at least eight tiles per list
+  const int most = (256 / SH::NCOL) & ~7;
+  if (nwg > most) nwg = most;
+  return nwg;
+}
+template <int K, int N>
+int launch_rows(const void* x, const void* dy, float* dw, float* db, long M, void* ws, long ws_bytes, int accumulate,
+                hipStream_t stream) {
+  using SH = RowsShape<K, N>;
+  RowsArgs a;
+  a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.M = (int)M;
+  a.ntile = (int)((M + SH::TT - 1) / SH::TT);
+  a.nwg = rows_nwg<K, N>(M);
+  const long main_bytes = (long)a.nwg * N * K * 4;
+  UNETK_CHECK_ARG(ws_bytes >= main_bytes + (long)a.nwg * N * 4, "linear_wgrad: workspace %ld < %ld bytes", ws_bytes,
+                  main_bytes + (long)a.nwg * N * 4);
+  a.slab = (float*)ws;
+  a.bias_slab = db != nullptr ? (float*)((char*)ws + main_bytes) : nullptr;
+  hipLaunchKernelGGL((lin_wgrad_rows_kernel<K, N>), dim3((unsigned)(a.nwg * SH::NCOL)), dim3(512), 0, stream, a);
+  UNETK_CHECK_LAUNCH();
+  const int nmain = cdiv((long)N * (K / 4), 16);
+  hipLaunchKernelGGL(lin_wgrad_reduce16_kernel, dim3((unsigned)(nmain + (db != nullptr ? cdiv(N, 16) : 0))), dim3(256), 0,
+                     stream, a.slab, dw, a.bias_slab, db, a.nwg, N, K, accumulate, nmain);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+#define UNETK_ROWS_SHAPES(X) X(96, 288) X(96, 96) X(96, 384) X(384, 96) X(192, 576) X(192, 192) X(192, 768) X(768, 192)
+
 template <int TM, int TN> int launch_gemm(GemmArgs a, hipStream_t stream) {
   constexpr int BM = 64 * TM;
   a.mtiles = cdiv(a.M, BM);
@@ -507,6 +814,24 @@ template <int TM, int TN> int launch_gemm(GemmArgs a, hipStream_t stream) {
 }
 
 }  // namespace
+
+// Hooks for unetk_linear_wgrad (conv_wgrad.hip): the whole-row kernel takes dense bfloat16 operands of the
+// shapes listed above with at least 2048 tokens per workgroup list.
+int64_t lin_wgrad_rows_workspace(int64_t M, int K, int N) {
+#define X(K_, N_) if (K == K_ && N == N_) { const int nwg = rows_nwg<K_, N_>(M); return nwg >= 8 ? (int64_t)nwg * N_ * (K_ + 1) * 4 : 0; }
+  UNETK_ROWS_SHAPES(X)
+#undef X
+  return 0;
+}
+int lin_wgrad_rows_try(const void* x, int ldx, const void* dy, int lddy, float* dw, float* db, int64_t M, int K, int N,
+                       void* ws, int64_t ws_bytes, int accumulate, hipStream_t stream, int* rc) {
+  if (ldx != K || lddy != N || M >= (1LL << 31) - 64 || getenv("UNETK_LINEAR_WGRAD_NO_ROWS") != nullptr) return 0;
+  if (lin_wgrad_rows_workspace(M, K, N) == 0) return 0;
+#define X(K_, N_) if (K == K_ && N == N_) { *rc = launch_rows<K_, N_>(x, dy, dw, db, M, ws, ws_bytes, accumulate, stream); return 1; }
+  UNETK_ROWS_SHAPES(X)
+#undef X
+  return 0;
+}
 
 extern "C" {
 
@@ -559,7 +884,9 @@ int unetk_token_wgrad_supported(int64_t M, int K, int N, int dtype) {
 
 int64_t unetk_token_wgrad_workspace_bytes(int64_t M, int K, int N) {
   const WgPlan p = plan_lin_wgrad(M, K, N);
-  return (int64_t)p.nsplit * p.N_pad * (p.K_pad + 1) * 4;
+  const int64_t tiles = (int64_t)p.nsplit * p.N_pad * (p.K_pad + 1) * 4;
+  const int64_t rows = lin_wgrad_rows_workspace(M, K, N);
+  return tiles > rows ? tiles : rows;
 }
 
 int unetk_token_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, float* dbias, int64_t M, int K,
@@ -575,6 +902,12 @@ int unetk_token_wgrad(const void* x, int ldx, const void* dy, int lddy, float* d
   UNETK_CHECK_ARG((int64_t)M * (ldx > lddy ? ldx : lddy) < (1LL << 31) * 32,
                   "token_wgrad: tensor too large for the 32-bit stage offsets");
   UNETK_CHECK_ARG(K % 4 == 0, "token_wgrad: K must be a multiple of 4");
+  {
+    // narrow layers over many tokens: the whole-row kernel (every token streamed once by one column of workgroups)
+    int rc = UNETK_OK;
+    if (lin_wgrad_rows_try(x, ldx, dy, lddy, dw, dbias, M, K, N, workspace, workspace_bytes, accumulate, stream, &rc))
+      return rc;
+  }
   const WgPlan p = plan_lin_wgrad(M, K, N);
   const int64_t main_bytes = (int64_t)p.nsplit * p.N_pad * p.K_pad * 4;
   const int64_t need = main_bytes + (int64_t)p.nsplit * p.N_pad * 4;
