@@ -282,6 +282,12 @@ int unetk_merge_gather(const void* x, void* out, int B, int H, int W, int C, int
  * [0,Co) of the (B,2h,2w,ldcat) concat buffer; backward=1 gathers the gradient back into tmp */
 int unetk_pixel_shuffle(void* tmp, void* cat, int ldcat, const float* bias, int B, int h, int w, int Co,
                         int backward, int dtype, unetk_stream_t stream);
+/* ConvTranspose2d(k=2,s=2) + bias forward (:501,521) in one launch: the token GEMM x (B,h,w,K) times the weight packed
+ * as for unetk_linear_fwd from the (4*up, K) matrix whose row (ky*2 + kx)*up + co is weight[:, co, ky, kx], with the
+ * pixel shuffle in the epilogue's store address: out[b][2y+ky][2x+kx][co] (channels [0,up) of a (B,2h,2w,ldo) buffer,
+ * e.g. the first half of the decoder's concat buffer).  bfloat16; shapes as unetk_linear_supported(B*h*w, K, 4*up, bn). */
+int unetk_convt2x2_fwd(const void* x, int ldx, const void* wpacked, void* out, int ldo, int B, int h, int w, int K,
+                       int up, int bn, int dtype, const float* bias, unetk_stream_t stream);
 /* WindowAttention + cyclic shift + window partition/reverse (:161-200, 241-269, 339-360), window 8,
  * head dim 32.  qkv: (B,He,We,3C) from the qkv linear; out: (B,He,We,C) before the proj linear.
  * table: relative_position_bias_table (225, heads) fp32. */

@@ -199,6 +199,29 @@ def test_token_weight_gradient_gemm(shape):
     assert torch.equal(dw3, dw) or (B * H * Wd >= 2048 and rel(dw3, dw) < 1e-6)
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 8, 768, 512), (1, 16, 12, 512, 256), (3, 5, 7, 256, 128), (2, 64, 64, 128, 64)])
+def test_conv_transpose_gemm_with_shuffled_stores(shape):
+    """ConvTranspose2d(k=2, s=2) + bias as one GEMM launch whose epilogue stores each value at its shuffled pixel:
+    against GEMM + pixel-shuffle kernel (which rounds to bfloat16 twice: before and after the bias) and
+    F.conv_transpose2d, to bf16 accuracy; ragged token counts, the first half of a wider concat buffer."""
+    from unet_amd import ops
+    B, h, w, K, up = shape
+    dt = torch.bfloat16
+    x = rnd((B, h, w, K), 41, dt, 0.7).to("cuda", dt)
+    wt = rnd((K, up, 2, 2), 42, dt, (1.0 / K) ** 0.5)                       # ConvTranspose2d weight (in, out, kh, kw)
+    bias = (torch.randn(up) * 0.1).cuda()
+    w2 = wt.cuda().permute(2, 3, 1, 0).reshape(4 * up, K).contiguous()
+    pk = ops.PackedConv(w2, dt)
+    assert ops.linear_supported(x, pk)
+    cat = torch.full((B, 2 * h, 2 * w, 2 * up), 3.0, dtype=dt, device="cuda")
+    ops.convT2x2_fwd(x, pk, bias, cat)
+    old = torch.full_like(cat, 3.0)
+    ops.pixel_shuffle(ops.linear_fwd(x, pk), old, bias, up)
+    assert torch.all(cat[..., up:] == 3.0) and rel(cat[..., :up], old[..., :up]) < 5e-3
+    ref = F.conv_transpose2d(x.float().cpu().permute(0, 3, 1, 2), wt, bias.cpu(), stride=2).permute(0, 2, 3, 1)
+    assert rel(cat[..., :up], ref) < 1e-2
+
+
 def build(dt):
     from unet_amd.swin import SwinUNet
     cfg = dict(swin_oracle.DEFAULT_CONFIG)

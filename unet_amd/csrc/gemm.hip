@@ -54,6 +54,9 @@ struct GemmArgs {
   int M, N, K, nchunks;
   int act;              // 0 none, 2 GELU(erf) (codes of unetk.h)
   int tok_per_sample;
+  // ConvTranspose2d(k=2, s=2) as a GEMM with N = 4 * up: channel n = (ky, kx, co) of token (b, y, x) is channel co
+  // of output pixel (b, 2y + ky, 2x + kx).  shuf_up = 0: a plain [M][ldo] result.
+  int shuf_up, shuf_w, shuf_hw;
   int mtiles, nby, tiles_per_xcd;
 };
 
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(256) void lin_gemm_kernel(GemmArgs a) {
   for (int p = 0; p < TN / 2; ++p) {
     const int c0 = n0 + 32 * p + 8 * q;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bias8[p][e] = a.bias != nullptr ? a.bias[c0 + e] : 0.f;
+    for (int e = 0; e < 8; ++e) bias8[p][e] = a.bias != nullptr ? a.bias[a.shuf_up ? (c0 + e) % a.shuf_up : c0 + e] : 0.f;
   }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -196,6 +199,11 @@ __global__ __launch_bounds__(256) void lin_gemm_kernel(GemmArgs a) {
     if (t >= a.M) continue;
     float keep = 1.f;
     if (a.keep != nullptr) keep = a.keep[t / a.tok_per_sample];
+    long shuf_row = 0;       // output pixel (b, 2y, 2x) of the token, in pixels of the (B, 2h, 2w) image
+    if (a.shuf_up) {
+      const int bb = t / a.shuf_hw, rem = t - bb * a.shuf_hw, y = rem / a.shuf_w, x = rem - y * a.shuf_w;
+      shuf_row = ((long)bb * 4 * a.shuf_hw) + (long)(2 * y) * (2 * a.shuf_w) + 2 * x;
+    }
 #pragma unroll
     for (int p = 0; p < TN / 2; ++p) {
       const int c0 = n0 + 32 * p + 8 * q;
@@ -204,6 +212,14 @@ __global__ __launch_bounds__(256) void lin_gemm_kernel(GemmArgs a) {
       for (int r = 0; r < 4; ++r) {
         v[r] = acc[i][2 * p][r] + bias8[p][r];
         v[4 + r] = acc[i][2 * p + 1][r] + bias8[p][4 + r];
+      }
+      if (a.shuf_up) {       // (uniform) the pixel shuffle of the transposed convolution, in the store address
+        const int qd = c0 / a.shuf_up, co = c0 - qd * a.shuf_up;
+        Vec16<bf16> o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.v[e] = from_f32<bf16>(v[e]);
+        store16(a.out + (shuf_row + (qd >> 1) * (2 * a.shuf_w) + (qd & 1)) * a.ldo + co, o);
+        continue;
       }
       if (a.aux != nullptr) {
         const Vec16<bf16> h = load16(a.aux + (long)t * a.ldaux + c0);
@@ -868,9 +884,33 @@ int unetk_linear_fwd(const void* x, int ldx, const void* wpacked, void* out, int
   a.ldx = ldx; a.ldo = ldo; a.ldo2 = ldo2; a.ldr = ldr; a.ldaux = ldaux;
   a.M = (int)M; a.N = N; a.K = K; a.nchunks = K / 32; a.act = act;
   a.tok_per_sample = resid_keep ? (int)tok_per_sample : 1;
+  a.shuf_up = a.shuf_w = a.shuf_hw = 0;
   // 128-token tiles, three workgroups per CU.  (256-token tiles, two per CU, measured slower on every
   // Swin shape, 64x64 tokens x 96 channels to 8x8 tokens x 3072 channels: these products are bound by
   // bytes and by how many workgroups cover each other's waits, not by the MFMA : LDS-read ratio.)
+  switch (bn) {
+    case 96: return launch_gemm<2, 6>(a, stream);
+    case 64: return launch_gemm<2, 4>(a, stream);
+    default: return launch_gemm<2, 2>(a, stream);
+  }
+}
+
+int unetk_convt2x2_fwd(const void* x, int ldx, const void* wpacked, void* out, int ldo, int B, int h, int w, int K,
+                       int up, int bn, int dtype, const float* bias, hipStream_t stream) {
+  UNETK_CHECK_ARG(x && wpacked && out && B > 0 && h > 0 && w > 0 && up > 0, "convt2x2_fwd: bad arguments");
+  const int64_t M = (int64_t)B * h * w;
+  const int N = 4 * up;
+  UNETK_CHECK_ARG(unetk_linear_supported(M, K, N, bn, dtype) && up % 8 == 0 && 4 * M < (1LL << 31),
+                  "convt2x2_fwd: unsupported shape or type (B=%d h=%d w=%d K=%d up=%d block %d dtype %d): bfloat16, K a "
+                  "multiple of 32, 4*up a multiple of its channel block, up a multiple of 8", B, h, w, K, up, bn, dtype);
+  UNETK_CHECK_ARG(ldx >= K && ldo >= up && ldx % 8 == 0 && ldo % 8 == 0 && ((uintptr_t)x % 16) == 0 &&
+                  ((uintptr_t)out % 16) == 0 && ((uintptr_t)wpacked % 16) == 0, "convt2x2_fwd: bad strides or alignment");
+  GemmArgs a;
+  a.x = (const bf16*)x; a.w = (const bf16*)wpacked; a.out = (bf16*)out; a.out2 = nullptr;
+  a.bias = bias; a.resid = nullptr; a.keep = nullptr; a.aux = nullptr;
+  a.ldx = ldx; a.ldo = ldo; a.ldo2 = 0; a.ldr = 0; a.ldaux = 0;
+  a.M = (int)M; a.N = N; a.K = K; a.nchunks = K / 32; a.act = UNETK_ACT_NONE; a.tok_per_sample = 1;
+  a.shuf_up = up; a.shuf_w = w; a.shuf_hw = h * w;
   switch (bn) {
     case 96: return launch_gemm<2, 6>(a, stream);
     case 64: return launch_gemm<2, 4>(a, stream);

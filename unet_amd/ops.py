@@ -258,6 +258,17 @@ def linear_fwd(x, pw: PackedConv, bias=None, act=0, resid=None, resid_keep=None,
     return (out, second) if out2 else out
 
 
+def convT2x2_fwd(x, pw: PackedConv, bias, out):
+    """ConvTranspose2d(k=2, s=2) + bias of channels-last x (B,h,w,K) into channels [0, up) of out (B,2h,2w,ld): one
+    GEMM launch whose epilogue stores every value at its shuffled pixel.  pw: the pack of the (4*up, K) matrix with
+    rows ordered (ky, kx, co).  The caller checks linear_supported(x, pw)."""
+    B, h, w, K = x.shape
+    up = pw.Co // 4
+    call("unetk_convt2x2_fwd", ptr(x), x.stride(-2), ptr(pw.data), ptr(out), out.stride(-2), B, h, w, K, up, pw.bn,
+         dtype_code(x.dtype), ptr(bias), stream())
+    return out
+
+
 def token_wgrad(x: torch.Tensor, dy: torch.Tensor, K: int, N: int, want_bias: bool = True):
     """(dw (N, K), db (N,) or None) fp32 of a linear layer over tokens, bfloat16 operands: x (..., ldx) and
     dy (..., lddy) channels-last with equally spaced token rows."""

@@ -422,8 +422,12 @@ def _decoder_fwd(dec, pre, x, skip, cx, training, save):
     has_skip = skip is not None and dec.skip_projection is not None
     cat = torch.empty((B, 2 * h, 2 * w, up * (2 if has_skip else 1)), dtype=cx.dt, device=x.device)
     w2 = dec.upsample.weight.permute(2, 3, 1, 0).reshape(4 * up, Cin)       # [(ky,kx,co)][ci]
-    tmp = _linear(x, w2, None, cx)
-    ops.pixel_shuffle(tmp, cat, dec.upsample.bias, up)
+    pk2 = cx.packed(w2)
+    if ops.linear_supported(x, pk2) and up % 8 == 0 and x.is_contiguous():
+        ops.convT2x2_fwd(x, pk2, dec.upsample.bias, cat)          # the pixel shuffle is the GEMM's store address
+    else:
+        tmp = _linear_launch(x, pk2)
+        ops.pixel_shuffle(tmp, cat, dec.upsample.bias, up)
     resized = None
     if has_skip:
         if skip.shape[1:3] == (2 * h, 2 * w):
