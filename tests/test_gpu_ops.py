@@ -249,6 +249,28 @@ def test_upsample_concat_fwd_bwd(dt, hw):
     assert rel(nchw(dlow), lr.grad) < TOL[dt]
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 8, 32), (1, 16, 24, 96), (3, 9, 13, 64), (2, 32, 32, 192), (1, 40, 8, 32)])
+def test_upsample_bwd_exact_2x_tiled(shape):
+    """The LDS-tiled backward of the exact 2x bilinear resize (bf16, channel slabs of 32): the same bits as the generic
+    gather kernel, and autograd of F.interpolate to bf16 accuracy; ragged tiles, wide strided gradients."""
+    import os
+    from unet_amd import ops
+    dt = torch.bfloat16
+    B, h, w, C1 = shape
+    lr = rnd((B, C1, h, w), 71, dt).requires_grad_(True)
+    g = rnd((B, C1 + 16, 2 * h, 2 * w), 72, dt)
+    F.interpolate(lr, size=(2 * h, 2 * w), mode="bilinear", align_corners=False).backward(g[:, :C1])
+    gd = nhwc(g, dt)                         # channels [0, C1) of a wider tensor: ldout > C1
+    dlow = ops.upsample_bwd(gd, C1, h, w)
+    os.environ["UNETK_UPSAMPLE_BWD_GENERIC"] = "1"
+    try:
+        generic = ops.upsample_bwd(gd, C1, h, w)
+    finally:
+        del os.environ["UNETK_UPSAMPLE_BWD_GENERIC"]
+    assert torch.equal(dlow, generic)
+    assert rel(nchw(dlow), lr.grad) < TOL[dt]
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("Co", [1, 3])
 def test_head1x1_fwd_bwd(dt, Co):

@@ -8,6 +8,7 @@
 // Per-channel reductions write per-workgroup partials that a second kernel sums in a
 // fixed order (in double), so results are bitwise reproducible; there are no atomics.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -798,6 +799,83 @@ __global__ void upsample2x_concat_kernel(const T* __restrict__ low, int h, int w
   }
 }
 
+
+// The exact 2x case (H = 2h, W = 2w; bfloat16, C1 a multiple of 32): a workgroup owns an 8 x 8 tile of dlow times 32
+// channels, stages the 18 x 18 pixels of dout it gathers from in LDS once (each element of dout would otherwise be
+// loaded by four threads), and every thread sums its sixteen candidates in the order of the generic kernel below
+// (rows, then columns, zero weights skipped): the same bits.  XCD x walks a contiguous eighth of the
+// (tile, channel slab) list, slabs fastest: the slabs of a tile share the cache lines of its pixels.
+__global__ __launch_bounds__(256) void upsample2x_bwd_tile_kernel(const bf16* __restrict__ dout, int ldout, int H, int W,
+                                                                   bf16* __restrict__ dlow, int B, int h, int w, int C1,
+                                                                   int tiles_x, int tiles_y, long nitems) {
+  using T = bf16;
+  constexpr int TP = 8, HP = 2 * TP + 2;                 // tile side in dlow, patch side in dout
+  __shared__ __attribute__((aligned(16))) char patch[HP * HP * 64];
+  const long item = xcd_contiguous_block();
+  if (item >= nitems) return;
+  const int nslab = C1 / 32;
+  const int slab = (int)(item % nslab);
+  long t = item / nslab;
+  const int tx = (int)(t % tiles_x);
+  t /= tiles_x;
+  const int ty = (int)(t % tiles_y);
+  const int b = (int)(t / tiles_y);
+  const int i0 = ty * TP, j0 = tx * TP;
+  const int Y0 = 2 * i0 - 1, X0 = 2 * j0 - 1;
+  const T* base = dout + (long)b * H * W * ldout + slab * 32;
+  for (int sidx = threadIdx.x; sidx < HP * HP * 4; sidx += 256) {
+    const int px = sidx >> 2, sl = sidx & 3;
+    const int py = px / HP, pxx = px - py * HP;
+    const int Y = Y0 + py, X = X0 + pxx;
+    Vec16<T> v = zero16<T>();
+    if ((unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W) v = load16(base + ((long)Y * W + X) * ldout + sl * 8);
+    *reinterpret_cast<Vec16<T>*>(patch + px * 64 + sl * 16) = v;
+  }
+  __syncthreads();
+  const int cg = threadIdx.x & 3, pix = threadIdx.x >> 2;
+  const int ti = pix >> 3, tj = pix & 7;
+  const int i = i0 + ti, j = j0 + tj;
+  if (i >= h || j >= w) return;
+  const float sy = 0.5f, sx = 0.5f;
+  // candidate rows / columns of dout, clipped as in the generic kernel
+  int ylo = 2 * i - 1, yhi = 2 * i + 2, xlo = 2 * j - 1, xhi = 2 * j + 2;
+  if (ylo < 0) ylo = 0;
+  if (xlo < 0) xlo = 0;
+  if (yhi > H - 1) yhi = H - 1;
+  if (xhi > W - 1) xhi = W - 1;
+  float wxs[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int x0, x1;
+    float lx;
+    src_index(sx, xlo + k, w, x0, x1, lx);
+    wxs[k] = (xlo + k <= xhi) ? (x0 == j ? 1.f - lx : 0.f) + (x1 == j ? lx : 0.f) : 0.f;
+  }
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  for (int y = ylo; y <= yhi; ++y) {
+    int y0, y1;
+    float ly;
+    src_index(sy, y, h, y0, y1, ly);
+    const float wy = (y0 == i ? 1.f - ly : 0.f) + (y1 == i ? ly : 0.f);
+    if (wy == 0.f) continue;
+    const char* row = patch + ((y - Y0) * HP + (xlo - X0)) * 64 + cg * 16;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (wxs[k] == 0.f) continue;
+      const Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(row + k * 64);
+      const float wgt = wy * wxs[k];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += wgt * to_f32(v.v[e]);
+    }
+  }
+  Vec16<T> o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o.v[e] = from_f32<T>(acc[e]);
+  store16(dlow + (((long)b * h + i) * w + j) * C1 + slab * 32 + cg * 8, o);
+}
+
 // dlow[b,i,j,:] = sum over output pixels (y,x) that read (i,j) of wy*wx*dout[b,y,x,:] (gather form)
 template <typename T>
 __global__ void upsample_bwd_kernel(const T* __restrict__ dout, int ldout, int H, int W, T* __restrict__ dlow,
@@ -1237,6 +1315,15 @@ int unetk_upsample_bwd(const void* dout, int ldout, int H, int W, void* dlow, in
   const float sy = (float)h / (float)H, sx = (float)w / (float)W;
   const long total = (long)B * h * w * (C1 / E);
   UNETK_CHECK_ARG(total < (1L << 31), "upsample_bwd: tensor too large");
+  if (dtype == UNETK_BF16 && H == 2 * h && W == 2 * w && C1 % 32 == 0 && h >= 8 && w >= 8 &&
+      getenv("UNETK_UPSAMPLE_BWD_GENERIC") == nullptr) {
+    const int tiles_x = cdiv(w, 8), tiles_y = cdiv(h, 8);
+    const long nitems = (long)B * tiles_x * tiles_y * (C1 / 32);
+    hipLaunchKernelGGL(upsample2x_bwd_tile_kernel, dim3((unsigned)(8 * cdiv(nitems, 8))), dim3(256), 0, stream,
+                       (const bf16*)dout, ldout, H, W, (bf16*)dlow, B, h, w, C1, tiles_x, tiles_y, nitems);
+    UNETK_CHECK_LAUNCH();
+    return UNETK_OK;
+  }
   DISPATCH_T(dtype, hipLaunchKernelGGL(upsample_bwd_kernel<T>, dim3(8 * cdiv(cdiv(total, 256), 8)), dim3(256), 0, stream,
                                        (const T*)dout, ldout, H, W, (T*)dlow, B, h, w, C1, sy, sx));
   UNETK_CHECK_LAUNCH();
