@@ -31,6 +31,8 @@ for name, hw, ci, co in layers:
     x = torch.randn(B, hw, hw, ci, device="cuda").to(dt)
     dy = torch.randn(B, hw, hw, co, device="cuda").to(dt)
     w = torch.randn(co, ci, 3, 3, device="cuda") * 0.05
+    if os.environ.get("ZERO"):              # all-zero operands: same instruction stream, less switching power
+        x.zero_(); dy.zero_(); w.zero_()
     pw, pwt = ops.PackedConv(w, dt), ops.PackedConv(w, dt, transpose=True)
     fl = 2.0 * B * hw * hw * ci * co * 9
     t_f = timeit(lambda: ops.conv_fwd(x, pw, want_stats=True))

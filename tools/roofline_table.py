@@ -7,6 +7,8 @@ HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB (gfx950 tallies the 128-b
 reads at 64 bytes); achieved TB/s = bytes / the kernel's average duration in the FETCH_SIZE pass,
 against 8 TB/s.  MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs):
 the share of SIMD-cycles in which the matrix pipe is busy, at the clock the chip actually held.
+clock_GHz = GRBM_GUI_ACTIVE / 8 / the kernel's duration in that pass: the clock the chip held under this
+kernel's load (it reads high on launches much shorter than 0.3 ms); the dense peaks assume 2.4 GHz.
 """
 import csv, sys, collections
 sys.path.insert(0, __file__.rsplit("/", 1)[0])
@@ -39,13 +41,16 @@ for k in fe:
     rd = 2.0 * fe[k]["FETCH_SIZE"] / c * 1024
     w = wr[k]["WRITE_SIZE"] / nw[k]["WRITE_SIZE"] * 1024
     us = df[k] / c / 1e3
-    util = None
+    util = clk = None
     if nm[k]["GRBM_GUI_ACTIVE"] and mf[k]["GRBM_GUI_ACTIVE"] > 0:
         util = mf[k]["SQ_VALU_MFMA_BUSY_CYCLES"] / (mf[k]["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
-    rows.append((df[k], k, c, us, rd, w, (rd + w) / (us * 1e-6) / 1e12, util))
+        if dm[k] > 0:
+            clk = mf[k]["GRBM_GUI_ACTIVE"] / 8.0 / dm[k]          # cycles per ns = GHz (sums over the same launches)
+    rows.append((df[k], k, c, us, rd, w, (rd + w) / (us * 1e-6) / 1e12, util, clk))
 rows.sort(reverse=True)
-out = [f"# {sys.argv[5]}", "kernel,launches,avg_us,hbm_read_MB_per_launch,hbm_write_MB_per_launch,achieved_TB_per_s,frac_of_8TBps,mfma_util"]
-for _, k, c, us, rd, w, tb, util in rows[:28]:
-    out.append(f"{k},{c},{us:.1f},{rd/1e6:.1f},{w/1e6:.1f},{tb:.2f},{tb/8:.3f},{'' if util is None else f'{util:.3f}'}")
+out = [f"# {sys.argv[5]}", "kernel,launches,avg_us,hbm_read_MB_per_launch,hbm_write_MB_per_launch,achieved_TB_per_s,frac_of_8TBps,mfma_util,clock_GHz"]
+for _, k, c, us, rd, w, tb, util, clk in rows[:28]:
+    out.append(f"{k},{c},{us:.1f},{rd/1e6:.1f},{w/1e6:.1f},{tb:.2f},{tb/8:.3f},{'' if util is None else f'{util:.3f}'},"
+               f"{'' if clk is None else f'{clk:.2f}'}")
 open(sys.argv[4], "w").write("\n".join(out) + "\n")
 print("\n".join(out))
