@@ -49,7 +49,10 @@ int unetk_conv_pack_weight(const float* w, void* packed, int Co, int Ci, int ks,
 /* Many weights in one launch.  jobs (device): 9 int64 per job = fp32 source pointer, destination
  * offset in elements from dst_base (16-byte aligned), Co, Ci, ks, bn, ceil(packed Ci / channels-per-chunk), transpose, packed
  * element count (unetk_conv_packed_elems); Co/Ci are the SOURCE tensor's.  blocks (device): per
- * workgroup two int32 = (job, 256-element block inside the job); nblocks of them. */
+ * workgroup two int32 = (job, group inside the job); nblocks of them.  A job has
+ * unetk_conv_pack_groups(packed Co, packed Ci, ks, bn, dtype) groups (packed = swapped when transpose=1),
+ * numbered from 0. */
+int unetk_conv_pack_groups(int Co, int Ci, int ks, int bn, int dtype);
 int unetk_conv_pack_weights(const int64_t* jobs, const int* blocks, int nblocks, void* dst_base, int dtype,
                             unetk_stream_t stream);
 int unetk_conv_num_tiles(int B, int H, int W, int ks);

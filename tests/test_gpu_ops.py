@@ -441,3 +441,23 @@ def test_conv_of_a_concatenation_read_in_place(dt, shape):
     both = torch.zeros((B, H, W, C1 + 8), dtype=dt, device="cuda")
     ops.upsample_into(x1[:, :H // 2 or 1, :W // 2 or 1].contiguous(), both)
     assert torch.equal(up, both[..., :C1])
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_batched_weight_packing_matches_single_packs(dt):
+    """One launch packs many weights group by group through LDS; every pack must hold the same bits as the
+    one-weight kernel's (forward and data-gradient form, 1x1 and 3x3, ragged channel counts, every block width)."""
+    from unet_amd import ops
+    shapes = [(48, 8, 3), (48, 48, 3), (96, 144, 3), (100, 40, 3), (24, 200, 3), (384, 1152, 3), (1, 48, 1), (3, 7, 3),
+              (288, 96, 1), (96, 384, 1), (50, 70, 1), (768, 192, 1), (64, 64, 3), (33, 31, 1)]
+    g = torch.Generator().manual_seed(5)
+    ws = [torch.randn(co, ci, ks, ks, generator=g).cuda() for co, ci, ks in shapes]
+    ws.append(torch.randn(192, 96, generator=g).cuda())               # a Linear weight (two dimensions)
+    jobs = [(w, tr) for tr in (False, True) for w in ws]
+    many = ops.pack_many(jobs, dt)
+    again = ops.pack_many(jobs, dt)                                     # the cached job table
+    for (w, tr), pk, pk2 in zip(jobs, many, again):
+        one = ops.PackedConv(w if w.dim() == 4 else w.view(*w.shape, 1, 1), dt, transpose=tr)
+        assert (pk.bn, pk.Co, pk.Ci, pk.ks) == (one.bn, one.Co, one.Ci, one.ks)
+        assert torch.equal(pk.data.view(torch.uint8), one.data.view(torch.uint8)), (tuple(w.shape), tr)
+        assert torch.equal(pk2.data.view(torch.uint8), one.data.view(torch.uint8)), (tuple(w.shape), tr)

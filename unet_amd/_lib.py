@@ -34,6 +34,7 @@ _SIGNATURES = {
     "unetk_conv_pick_bn": (I, [I]),
     "unetk_conv_packed_elems": (L, [I, I, I, I, I]),
     "unetk_conv_pack_weight": (I, [P, P, I, I, I, I, I, I, P]),
+    "unetk_conv_pack_groups": (I, [I, I, I, I, I]),
     "unetk_conv_pack_weights": (I, [P, P, I, P, I, P]),
     "unetk_conv_stats_rows": (I, [I] * 10),
     "unetk_conv_num_tiles": (I, [I, I, I, I]),

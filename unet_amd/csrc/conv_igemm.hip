@@ -1484,37 +1484,100 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
 // Many weights in one launch (a training step re-packs every conv / linear weight, forward and
 // data-gradient form: dozens of tiny launches otherwise).  jobs: 9 int64 per job = source pointer,
 // destination offset (elements from dst_base), Co, Ci, ks, bn, chunks, transpose, packed elements;
-// blocks: per workgroup (job, 256-element block inside the job).
-template <typename T>
-__global__ void pack_weights_batched_kernel(const long* __restrict__ jobs, const int* __restrict__ blocks,
-                                            T* __restrict__ dst_base, int kc) {
-  const int job = blocks[2 * blockIdx.x], blk = blocks[2 * blockIdx.x + 1];
-  const long* j = jobs + 9L * job;
-  const float* w = reinterpret_cast<const float*>(j[0]);
-  T* dst = dst_base + j[1];
-  const int Co = (int)j[2], Ci = (int)j[3], ks = (int)j[4], bn = (int)j[5], nchunks = (int)j[6], transpose = (int)j[7];
-  const long total = j[8];
-  const long idx = (long)blk * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int taps = ks * ks;
-  long t = idx;
-  const int k = t % kc;
-  t /= kc;
-  const int row = t % bn;
-  t /= bn;
-  const int tap = t % taps;
-  t /= taps;
-  const int ch = t % nchunks;
-  const int nb = t / nchunks;
-  const int n = nb * bn + row;
-  const int c = ch * kc + k;
-  float v = 0.f;
+// blocks: per workgroup (job, group inside the job).  A group is RG packed rows (16 for 3x3, the whole
+// bn-row block for 1x1) x one channel chunk x all taps: its source is RG runs of kc*taps consecutive
+// floats (forward form) or kc runs of RG*taps consecutive floats (data-gradient form), read once and
+// coalesced into LDS, and its destination is one run of RG*kc elements per tap.  (The one-thread-per-
+// destination-element form above gathers 4-byte words 36 bytes apart for a 3x3 weight and a whole source
+// row apart for a data-gradient form: 3-6x slower on the weights of a training step.)
+inline int pack_group_rows(int ks, int bn) { return ks == 1 ? bn : 16; }
+constexpr int PACK_LDS_FLOATS = 32 * (16 * 9 + 1);      // the data-gradient form of a 3x3 bf16 group, padded rows
+static_assert(PACK_LDS_FLOATS >= 32 * (96 + 1) && PACK_LDS_FLOATS >= 16 * 32 * 9, "every group form fits");
+
+// floor(e / d) for 0 <= e < 2^13, 0 < d < 2^11 by one multiplication (inv = 1 / d): (e + 0.5) / d is at least
+// 0.5 / d away from an integer, far more than the rounding of the product
+__device__ __forceinline__ int small_div(int e, float inv) { return (int)(((float)e + 0.5f) * inv); }
+
+template <typename T, int TAPS>
+__device__ __forceinline__ void pack_group(const float* __restrict__ w, T* __restrict__ dst, float* buf, int Co, int Ci,
+                                           int bn, int nchunks, int transpose, int g) {
+  constexpr int KC = MMA<T>::KC;
+  const int RG = TAPS == 1 ? bn : 16, gpb = bn / RG;
+  const int rg = g % gpb, ch = (g / gpb) % nchunks, nb = g / (gpb * nchunks);
+  const int n0 = nb * bn + rg * RG;          // first packed row (output channel of the packed conv)
+  const int c0 = ch * KC;                    // first packed input channel
+  const int tid = threadIdx.x;
+  // 1x1 weights whose rows start on 16-byte boundaries move as float4 (four times fewer load instructions: the
+  // loads, not the bytes, bound this kernel); the 36-byte taps of a 3x3 weight keep no such alignment
+  const bool vec = TAPS == 1 && (Ci & 3) == 0 && ((uintptr_t)w & 15) == 0;
   if (!transpose) {
-    if (n < Co && c < Ci) v = w[((long)n * Ci + c) * taps + tap];
+    constexpr int RUN = KC * TAPS;           // floats of one source row that belong to the chunk
+    if (vec) {
+      for (int e = tid * 4; e < RG * RUN; e += 1024) {
+        const int r = e / RUN, q = e % RUN;
+        const int n = n0 + r, c = c0 + q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < Co && c < Ci) v = *reinterpret_cast<const float4*>(w + (long)n * Ci + c);     // (Ci % 4 == 0: all four inside)
+        *reinterpret_cast<float4*>(buf + e) = v;
+      }
+    } else {
+      for (int e = tid; e < RG * RUN; e += 256) {
+        const int r = e / RUN, q = e % RUN;
+        const int n = n0 + r, c = c0 + q / TAPS;
+        buf[e] = (n < Co && c < Ci) ? w[((long)n * Ci + c0) * TAPS + q] : 0.f;
+      }
+    }
   } else {
-    if (n < Ci && c < Co) v = w[((long)c * Ci + n) * taps + (taps - 1 - tap)];
+    // packed row n = source input channel, packed channel c = source output channel, taps flipped
+    const int run = RG * TAPS, pitch = run + 1;
+    const float inv = 1.f / (float)run;
+    if (vec) {                               // (RG = bn is a multiple of 16: a run is whole float4s)
+      for (int e = tid * 4; e < KC * run; e += 1024) {
+        const int k = small_div(e, inv), q = e - k * run;
+        const int c = c0 + k, n = n0 + q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < Co && n < Ci) v = *reinterpret_cast<const float4*>(w + (long)c * Ci + n);
+        float* b = buf + k * pitch + q;
+        b[0] = v.x; b[1] = v.y; b[2] = v.z; b[3] = v.w;
+      }
+    } else {
+      for (int e = tid; e < KC * run; e += 256) {
+        const int k = small_div(e, inv), q = e - k * run;
+        const int c = c0 + k, n = n0 + q / TAPS;
+        buf[k * pitch + q] = (c < Co && n < Ci) ? w[((long)c * Ci + n0) * TAPS + q] : 0.f;
+      }
+    }
   }
-  dst[idx] = from_f32<T>(v);
+  __syncthreads();
+  constexpr int E = Vec16<T>::N;             // destination elements per 16-byte store (KC is a multiple)
+  const int per_tap = RG * KC;
+  const float inv_pt = 1.f / (float)per_tap;
+  const long tap_stride = (long)bn * KC;
+  T* __restrict__ d0 = dst + ((long)(nb * nchunks + ch) * TAPS * bn + rg * RG) * KC;
+  for (int i = tid * E; i < per_tap * TAPS; i += 256 * E) {
+    const int tap = TAPS == 1 ? 0 : small_div(i, inv_pt), rem = i - tap * per_tap;
+    const int r = rem / KC, k = rem % KC;
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      o.v[e] = from_f32<T>(transpose ? buf[(k + e) * (RG * TAPS + 1) + r * TAPS + (TAPS - 1 - tap)]
+                                     : buf[(r * KC + k + e) * TAPS + tap]);
+    store16(d0 + tap * tap_stride + rem, o);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const long* __restrict__ jobs,
+                                                                   const int* __restrict__ blocks,
+                                                                   T* __restrict__ dst_base) {
+  __shared__ __attribute__((aligned(16))) float buf[PACK_LDS_FLOATS];
+  const int job = blocks[2 * blockIdx.x], g = blocks[2 * blockIdx.x + 1];
+  const long* j = jobs + 9L * job;
+  const float* __restrict__ w = reinterpret_cast<const float*>(j[0]);
+  T* __restrict__ dst = dst_base + j[1];
+  const int Co = (int)j[2], Ci = (int)j[3], ks = (int)j[4], bn = (int)j[5], nchunks = (int)j[6], transpose = (int)j[7];
+  if (ks == 1) pack_group<T, 1>(w, dst, buf, Co, Ci, bn, nchunks, transpose, g);
+  else         pack_group<T, 9>(w, dst, buf, Co, Ci, bn, nchunks, transpose, g);
 }
 
 // up to 48 -> 48 channels, bf16, 3x3 (the full-resolution layers): the persistent whole-pixel kernel (it has
@@ -1657,16 +1720,21 @@ int unetk_conv_pack_weight(const float* w, void* packed, int Co, int Ci, int ks,
   return UNETK_OK;
 }
 
+int unetk_conv_pack_groups(int Co, int Ci, int ks, int bn, int dtype) {
+  if (ks != 1 && ks != 3) return 0;
+  return cdiv(Co, bn) * cdiv(Ci, kc_of(dtype)) * (bn / pack_group_rows(ks, bn));
+}
+
 int unetk_conv_pack_weights(const int64_t* jobs, const int* blocks, int nblocks, void* dst_base, int dtype,
                             hipStream_t stream) {
   UNETK_CHECK_ARG(jobs && blocks && nblocks > 0 && dst_base && ((uintptr_t)dst_base % 16) == 0, "conv_pack_weights: bad arguments");
   UNETK_CHECK_ARG(dtype == UNETK_F32 || dtype == UNETK_BF16, "conv_pack_weights: bad dtype %d", dtype);
   if (dtype == UNETK_BF16)
     hipLaunchKernelGGL(pack_weights_batched_kernel<bf16>, dim3(nblocks), dim3(256), 0, stream,
-                       reinterpret_cast<const long*>(jobs), blocks, (bf16*)dst_base, kc_of(dtype));
+                       reinterpret_cast<const long*>(jobs), blocks, (bf16*)dst_base);
   else
     hipLaunchKernelGGL(pack_weights_batched_kernel<float>, dim3(nblocks), dim3(256), 0, stream,
-                       reinterpret_cast<const long*>(jobs), blocks, (float*)dst_base, kc_of(dtype));
+                       reinterpret_cast<const long*>(jobs), blocks, (float*)dst_base);
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }

@@ -136,7 +136,7 @@ def pack_many(weights, dt):
     hit = _PACK_TABLES.get(key)
     if hit is None:
         jobs_h = torch.from_numpy(np.asarray(rows, dtype=np.int64).reshape(-1)).pin_memory()
-        nblk = np.asarray([-(-r[8] // 256) for r in rows], dtype=np.int64)
+        nblk = np.asarray([lib.unetk_conv_pack_groups(m[0], m[1], m[2], m[3], dtype_code(dt)) for m in metas], dtype=np.int64)
         job_of = np.repeat(np.arange(len(rows), dtype=np.int32), nblk)
         first = np.repeat(np.cumsum(nblk) - nblk, nblk)
         blocks = np.stack([job_of, (np.arange(int(nblk.sum())) - first).astype(np.int32)], 1).astype(np.int32)
