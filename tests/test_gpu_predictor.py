@@ -146,3 +146,27 @@ def test_load_model_and_save_prediction(tmp_path):
     with netcdf_file(path, "r", mmap=False) as nc:
         assert np.array_equal(nc.variables["prediction_baseline"][:], out)
         assert np.array_equal(nc.variables["lat"][:], np.arange(80)) and np.array_equal(nc.variables["lon"][:], np.arange(72))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("lat,lon,P,nvar", [(70, 96, 32, 4), (64, 100, 16, 4), (50, 61, 8, 4), (40, 48, 12, 3), (33, 64, 16, 5)])
+def test_tile_gather_every_alignment(dt, lat, lon, P, nvar):
+    """The batched gather (large_area_predictor.py:141-156: slice, NaN -> 0, stack) against torch indexing, bit for bit:
+    tile columns that are and are not multiples of four floats, row pitches that are not, NaNs and infinities."""
+    from unet_amd import ops
+    from unet_amd._lib import call, ptr, dtype_code, stream
+    g = torch.Generator().manual_seed(lat * lon + P)
+    feats = torch.randn(nvar, lat, lon, generator=g)
+    feats[torch.rand(nvar, lat, lon, generator=g) < 0.05] = float("nan")
+    feats[0, 3, 5] = float("inf"); feats[nvar - 1, 7, 2] = float("-inf")
+    pos = [(0, 0), (lat - P, lon - P), (1, 4), (5, 3), (2, 1), (lat - P, 8), (3, lon - P)]
+    pos = [(i, j) for i, j in pos if 0 <= i <= lat - P and 0 <= j <= lon - P]
+    ld = ops.pad_channels(nvar, dt)
+    fd = feats.cuda()
+    pd = torch.tensor(pos, dtype=torch.int32).reshape(-1).cuda()
+    out = torch.full((len(pos), P, P, ld), 7.0, dtype=dt, device="cuda")
+    call("unetk_tile_gather", ptr(fd), nvar, lat, lon, ptr(pd), len(pos), P, ptr(out), ld, dtype_code(dt), stream())
+    want = torch.zeros((len(pos), P, P, ld), dtype=dt)
+    for t, (i, j) in enumerate(pos):
+        want[t, :, :, :nvar] = torch.nan_to_num(feats[:, i:i + P, j:j + P]).permute(1, 2, 0).to(dt)
+    assert torch.equal(out.cpu().view(torch.uint8), want.view(torch.uint8))

@@ -49,6 +49,48 @@ __global__ __launch_bounds__(256) void tile_valid_kernel(const float* __restrict
   }
 }
 
+// The usual shape of tile_gather (one 16-byte pixel, tile columns and row pitch multiples of four floats): a thread
+// moves four neighbouring pixels, one float4 per variable in and four 16-byte pixels out.  A tile whose first column
+// is not a multiple of four takes the scalar loads.
+template <typename T>
+__global__ void tile_gather_quad_kernel(const float* __restrict__ feats, int nvar, int lat, int lon,
+                                        const int* __restrict__ pos, int n, int P, T* __restrict__ out) {
+  constexpr int E = Vec16<T>::N;
+  const int Q = P / 4;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)n * P * Q) return;
+  const int t = idx / ((long)P * Q);
+  const int r = idx - (long)t * P * Q;
+  const int y = r / Q, x = (r - y * Q) * 4;
+  const int j0 = pos[2 * t + 1];
+  const long src = (long)(pos[2 * t] + y) * lon + j0 + x;
+  float v[E][4];
+#pragma unroll
+  for (int c = 0; c < E; ++c) {
+    if (c < nvar) {
+      const float* f = feats + (long)c * lat * lon + src;
+      if ((j0 & 3) == 0) {
+        const float4 q = *reinterpret_cast<const float4*>(f);
+        v[c][0] = q.x; v[c][1] = q.y; v[c][2] = q.z; v[c][3] = q.w;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[c][k] = f[k];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[c][k] = 0.f;
+    }
+  }
+  T* o = out + (((long)t * P + y) * P + x) * E;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    Vec16<T> pix;
+#pragma unroll
+    for (int c = 0; c < E; ++c) pix.v[c] = from_f32<T>(c < nvar ? nan_to_num(v[c][k]) : 0.f);
+    store16(o + k * E, pix);
+  }
+}
+
 // out[n][y][x][0:nvar] = nan_to_num(feats[v][i0+y][j0+x]); channels nvar..ld-1 are zero
 template <typename T>
 __global__ void tile_gather_kernel(const float* __restrict__ feats, int nvar, int lat, int lon,
@@ -60,6 +102,17 @@ __global__ void tile_gather_kernel(const float* __restrict__ feats, int nvar, in
   const int y = r / P, x = r - y * P;
   const long src = (long)(pos[2 * t] + y) * lon + pos[2 * t + 1] + x;
   T* o = out + idx * ld;
+  if (ld == Vec16<T>::N && ((uintptr_t)out & 15) == 0) {     // the usual case (4 variables): one 16-byte store per pixel
+    Vec16<T> pix;
+#pragma unroll
+    for (int c = 0; c < Vec16<T>::N; ++c) {
+      float v = 0.f;
+      if (c < nvar) v = nan_to_num(feats[(long)c * lat * lon + src]);
+      pix.v[c] = from_f32<T>(v);
+    }
+    store16(o, pix);
+    return;
+  }
   for (int c = 0; c < ld; ++c) {
     float v = 0.f;
     if (c < nvar) v = nan_to_num(feats[(long)c * lat * lon + src]);
@@ -133,6 +186,18 @@ int unetk_tile_gather(const float* feats, int nvar, int lat, int lon, const int*
   UNETK_CHECK_ARG(feats && pos && out && n > 0 && ld >= nvar, "tile_gather: bad arguments");
   UNETK_CHECK_ARG(dtype == UNETK_F32 || dtype == UNETK_BF16, "tile_gather: bad dtype %d", dtype);
   const long total = (long)n * P * P;
+  const int epp = dtype == UNETK_BF16 ? 8 : 4;
+  if (ld == epp && nvar <= epp && P % 4 == 0 && lon % 4 == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)feats % 16) == 0 &&
+      ((long)lat * lon) % 4 == 0) {
+    if (dtype == UNETK_BF16)
+      hipLaunchKernelGGL(tile_gather_quad_kernel<bf16>, dim3(cdiv(total / 4, 256)), dim3(256), 0, stream, feats, nvar, lat,
+                         lon, pos, n, P, (bf16*)out);
+    else
+      hipLaunchKernelGGL(tile_gather_quad_kernel<float>, dim3(cdiv(total / 4, 256)), dim3(256), 0, stream, feats, nvar, lat,
+                         lon, pos, n, P, (float*)out);
+    UNETK_CHECK_LAUNCH();
+    return UNETK_OK;
+  }
   if (dtype == UNETK_BF16)
     hipLaunchKernelGGL(tile_gather_kernel<bf16>, dim3(cdiv(total, 256)), dim3(256), 0, stream, feats, nvar, lat,
                        lon, pos, n, P, (bf16*)out, ld);
