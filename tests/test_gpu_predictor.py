@@ -170,3 +170,38 @@ def test_tile_gather_every_alignment(dt, lat, lon, P, nvar):
     for t, (i, j) in enumerate(pos):
         want[t, :, :, :nvar] = torch.nan_to_num(feats[:, i:i + P, j:j + P]).permute(1, 2, 0).to(dt)
     assert torch.equal(out.cpu().view(torch.uint8), want.view(torch.uint8))
+
+
+def test_blend_four_pixels_per_thread_same_bits(monkeypatch):
+    """The blend kernel that moves four pixels per thread against the one-pixel kernel (UNETK_BLEND_SCALAR) and against
+    numpy's sequential `acc[win] += pred * w` (large_area_predictor.py:196-203): product and sum round separately."""
+    from unet_amd._lib import call, ptr, stream
+    P, S, lat, lon = 64, 32, 200, 168
+    nti, ntj = (lat - P) // S + 1, (lon - P) // S + 1
+    n = nti * ntj
+    g = torch.Generator().manual_seed(1)
+    pred = torch.randn(n, P, P, generator=g)
+    pred[3, 5, 7] = float("nan")
+    wk = torch.rand(P, P, generator=g)
+    slot = torch.arange(n, dtype=torch.int32).cuda()
+    pd, wd = pred.cuda(), wk.cuda()
+    outs = []
+    for scalar in (True, False):
+        if scalar:
+            monkeypatch.setenv("UNETK_BLEND_SCALAR", "1")
+        else:
+            monkeypatch.delenv("UNETK_BLEND_SCALAR")
+        acc = torch.zeros(lat, lon, device="cuda")
+        cnt = torch.zeros(lat, lon, device="cuda")
+        call("unetk_blend_accumulate", ptr(pd), ptr(wd), ptr(slot), 0, n, nti, ntj, P, S, ptr(acc), ptr(cnt), lat, lon,
+             0, lat, stream())
+        outs.append((acc.cpu().numpy(), cnt.cpu().numpy()))
+    want_a = np.zeros((lat, lon), np.float32)
+    want_c = np.zeros((lat, lon), np.float32)
+    pn, wn = np.nan_to_num(pred.numpy()), wk.numpy()
+    for t in range(n):
+        i, j = (t // ntj) * S, (t % ntj) * S
+        want_a[i:i + P, j:j + P] += pn[t] * wn
+        want_c[i:i + P, j:j + P] += wn
+    for a, c in outs:
+        assert np.array_equal(a, want_a) and np.array_equal(c, want_c)

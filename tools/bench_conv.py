@@ -23,6 +23,9 @@ def timeit(fn, n=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 
+if os.environ.get("SHAPES") == "swin":   # the 3x3 convs of the Swin-UNet decoder at batch 64
+    layers = [("d0.0", 16, 768, 512), ("d0.1", 16, 512, 512), ("d1.0", 32, 512, 256), ("d1.1", 32, 256, 256),
+              ("d2.0", 64, 256, 128), ("d2.1", 64, 128, 128), ("d3.0", 128, 64, 64), ("d3.1", 128, 64, 64), ("final", 128, 64, 32)]
 only = os.environ.get("LAYERS")          # e.g. LAYERS=dec3.0,enc2.3 to profile a few shapes
 if only:
     layers = [l for l in layers if l[0] in only.split(",")]
