@@ -1017,6 +1017,7 @@ __global__ void resize_planes_bwd_kernel(const float* __restrict__ dout, float* 
 
 // ------------------------------------------------------------------ final 1x1 convolution (few outputs)
 // out[b,o,hw] = bias[o] + sum_c x[b,hw,c] * w[o,c]      (out is NCHW fp32)
+constexpr int HEAD_PIX = 4;
 template <typename T>
 __global__ __launch_bounds__(256) void head1x1_fwd_kernel(const T* __restrict__ x, int ldx,
                                                           const float* __restrict__ w,
@@ -1025,30 +1026,42 @@ __global__ __launch_bounds__(256) void head1x1_fwd_kernel(const T* __restrict__ 
                                                           int Co) {
   // Threads are (pixel lane, channel group): consecutive threads read consecutive 16-byte vectors of a
   // pixel row, so the loads are coalesced; a pixel's partial dot products meet in LDS and its first
-  // thread adds them in channel order.
+  // thread adds them in channel order.  A workgroup takes HEAD_PIX groups of pixels at once: their loads
+  // are in flight together and share the two barriers.
   constexpr int E = Vec16<T>::N;
-  extern __shared__ float wl[];              // [Co][C] weights, then [256] partial sums
+  extern __shared__ float wl[];              // [Co][C] weights, then [HEAD_PIX][256] partial sums
   float* red = wl + Co * C;
   for (int i = threadIdx.x; i < Co * C; i += blockDim.x) wl[i] = w[i];
   const int CG = C / E;
   const int lanes = 256 / CG;
   const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
-  const long p = (long)blockIdx.x * lanes + pl;
-  const bool live = pl < lanes && p < npix;
-  Vec16<T> v = zero16<T>();
-  if (live) v = load16(x + p * ldx + cg * E);
+  const long p0 = (long)blockIdx.x * lanes * HEAD_PIX + pl;
+  Vec16<T> v[HEAD_PIX];
+#pragma unroll
+  for (int k = 0; k < HEAD_PIX; ++k) {
+    const long p = p0 + (long)k * lanes;
+    v[k] = (pl < lanes && p < npix) ? load16(x + p * ldx + cg * E) : zero16<T>();
+  }
   __syncthreads();
   for (int o = 0; o < Co; ++o) {
-    float s = 0.f;
 #pragma unroll
-    for (int e = 0; e < E; ++e) s += to_f32(v.v[e]) * wl[o * C + cg * E + e];
-    red[threadIdx.x] = s;
+    for (int k = 0; k < HEAD_PIX; ++k) {
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < E; ++e) s += to_f32(v[k].v[e]) * wl[o * C + cg * E + e];
+      red[k * 256 + threadIdx.x] = s;
+    }
     __syncthreads();
-    if (live && cg == 0) {
-      float t = bias ? bias[o] : 0.f;
-      for (int k = 0; k < CG; ++k) t += red[threadIdx.x + k];
-      const int b = p / hw;
-      out[((long)b * Co + o) * hw + (p - (long)b * hw)] = t;
+    if (pl < lanes && cg == 0) {
+#pragma unroll
+      for (int k = 0; k < HEAD_PIX; ++k) {
+        const long p = p0 + (long)k * lanes;
+        if (p >= npix) continue;
+        float t = bias ? bias[o] : 0.f;
+        for (int j = 0; j < CG; ++j) t += red[k * 256 + threadIdx.x + j];
+        const long b = p / hw;
+        out[(b * Co + o) * hw + (p - b * hw)] = t;
+      }
     }
     __syncthreads();
   }
@@ -1360,8 +1373,8 @@ int unetk_head1x1_fwd(const void* x, int ldx, const float* w, const float* bias,
   UNETK_CHECK_ARG(C / E <= 256, "head1x1_fwd: too many channels (%d)", C);
   const long npix = (long)B * H * W;
   const int lanes = 256 / (C / E);           // pixels per workgroup
-  DISPATCH_T(dtype, hipLaunchKernelGGL(head1x1_fwd_kernel<T>, dim3((unsigned)cdiv(npix, lanes)), dim3(256),
-                                       (size_t)(Co * C + 256) * 4, stream, (const T*)x, ldx, w, bias, out, npix,
+  DISPATCH_T(dtype, hipLaunchKernelGGL(head1x1_fwd_kernel<T>, dim3((unsigned)cdiv(npix, (long)lanes * HEAD_PIX)), dim3(256),
+                                       (size_t)(Co * C + HEAD_PIX * 256) * 4, stream, (const T*)x, ldx, w, bias, out, npix,
                                        (long)H * W, C, Co));
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
