@@ -206,12 +206,13 @@ class _Ctx:
     for training the data-gradient form) and looked up by the parameter's address; anything not
     found there (a reshaped copy) is packed on the spot.  Owned by the autograd node of the step
     (or dropped after an inference call): interleaved models or steps cannot see each other's packs."""
-    __slots__ = ("dt", "pool", "side", "held")
+    __slots__ = ("dt", "pool", "side", "held", "tracked")
 
     def __init__(self, model, training):
         self.dt = dt = model.compute_dtype
         self.side = None        # set by the backward pass: the stream the weight gradients run on
         self.held = []
+        self.tracked = []       # BatchNorm step counters of this forward: advanced by one launch at its end
         ws = []
         for m in model.modules():
             if isinstance(m, (nn.Linear, nn.Conv2d)):
@@ -395,7 +396,7 @@ def _conv_bn_relu_fwd(conv, bn, t, cx, training, save, tag):
                                            bn.running_var, bn.eps, bn.momentum if bn.momentum is not None else 0.1)
     if conv.bias is not None:
         bn.running_mean.add_(conv.bias.detach(), alpha=bn.momentum if bn.momentum is not None else 0.1)
-    bn.num_batches_tracked += 1
+    cx.tracked.append(bn.num_batches_tracked)
     a, _ = ops.bn_act_fwd(y, sc, sh, None, relu=True)
     if save is not None:
         save.append(("cbr", conv, bn, tag, (t, y, mean, invstd, sc, sh)))
@@ -509,6 +510,9 @@ def _forward(model, x, drop_path, save):
     fc = model.final_conv
     f = _conv_bn_relu_fwd(fc[0], fc[1], d, cx, training, save, ("final_conv.0", "final_conv.1"))
     out = ops.head1x1_fwd(f, fc[3].weight, fc[3].bias)
+    if cx.tracked:
+        torch._foreach_add_(cx.tracked, 1)
+        cx.tracked = []
     if training:
         save.append(("head", f))
     return out

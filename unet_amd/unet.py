@@ -219,6 +219,7 @@ class _UNetTrainFn(torch.autograd.Function):
         # forward and data-gradient forms of all 18 weights: one launch
         pk, ctx.pkT = _pack_all(model, dt, "both")
         saved = {}
+        tracked = []                 # the BatchNorm step counters: advanced by one launch at the end
         B = x.shape[0]
         h = ops.nchw_to_nhwc(x.detach(), dt)
         saved["x"] = h
@@ -243,7 +244,7 @@ class _UNetTrainFn(torch.autograd.Function):
                     bn.running_var if bn.track_running_stats else None, bn.eps,
                     bn.momentum if bn.momentum is not None else 0.1)
                 if bn.track_running_stats:
-                    bn.num_batches_tracked += 1
+                    tracked.append(bn.num_batches_tracked)
                 last = u == 1
                 if last and pool and _reads_pair(cat_c1):
                     a, pooled, argmax = ops.bn_act_fwd(y, sc, sh, keep, relu=True, pool=True, want_argmax=True)
@@ -278,6 +279,8 @@ class _UNetTrainFn(torch.autograd.Function):
             d, _, _ = block(name, joined, masks[5 + i], False)
         saved["head_in"] = d
         out = ops.head1x1_fwd(d, model.conv.weight, model.conv.bias)
+        if tracked:
+            torch._foreach_add_(tracked, 1)
         ctx.model = model
         ctx.saved = saved
         ctx.versions = [p._version for p in params]
