@@ -263,6 +263,17 @@ int unetk_token_reduce_num_partials(int64_t ntok);
 int unetk_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                         const void* add, void* dx, float* dgamma, float* dbeta, float* partials, int64_t ntok,
                         int C, int dtype, unetk_stream_t stream);
+/* The same backward in two halves, so that the small column sums of all LayerNorms of a backward pass
+ * (swin_unet_model.py:289,295: two per block) can be taken by ONE launch at its end.
+ * unetk_layernorm_bwd_partials writes dx and unetk_layernorm_bwd_rows(ntok, C, dtype) rows of partials
+ * [row][2][C] (0 rows: the shape has no one-pass form, use unetk_layernorm_bwd);
+ * unetk_partial_sums_batched sums njobs such tables: jobs (device) = five int64 per job: partials, rows, C,
+ * dgamma, dbeta (0 = not wanted); max_C = the largest C among them.  Same bits as unetk_layernorm_bwd. */
+int unetk_layernorm_bwd_rows(int64_t ntok, int C, int dtype);
+int unetk_layernorm_bwd_partials(const void* dy, const void* x, const float* gamma, const float* mean,
+                                 const float* rstd, const void* add, void* dx, float* partials, int64_t ntok, int C,
+                                 int dtype, unetk_stream_t stream);
+int unetk_partial_sums_batched(const int64_t* jobs, int njobs, int max_C, unetk_stream_t stream);
 /* bias gradients of the linears: out[c] = sum over tokens */
 int unetk_channel_sum(const void* x, int ld, int64_t ntok, int C, float* out, float* partials, int dtype,
                       unetk_stream_t stream);

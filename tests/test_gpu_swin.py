@@ -419,3 +419,25 @@ def test_swin_seeded_droppath_and_errors(golden):
     from unet_amd.swin import SwinUNet
     with pytest.raises(ValueError):
         SwinUNet(dict(cfg, window_size=7))
+
+
+@pytest.mark.parametrize("C,ntok", [(96, 4096), (192, 1000), (384, 333), (768, 64)])
+def test_layernorm_backward_deferred_sums_same_bits(C, ntok):
+    """The two-halves LayerNorm backward (dx + partial tables now, all dgamma / dbeta sums by one launch later)
+    against the one-call form: same dx, same dgamma, same dbeta, bit for bit."""
+    from unet_amd import ops
+    g = torch.Generator().manual_seed(C + ntok)
+    dt = torch.bfloat16
+    x = torch.randn(1, ntok, C, generator=g).cuda().to(dt)
+    dy = torch.randn(1, ntok, C, generator=g).cuda().to(dt)
+    add = torch.randn(1, ntok, C, generator=g).cuda().to(dt)
+    gamma = torch.randn(C, generator=g).cuda()
+    beta = torch.zeros(C).cuda()
+    _, mean, rstd = ops.layernorm_fwd(x, gamma, beta, 1e-5)
+    want = ops.layernorm_bwd(dy, x, gamma, mean, rstd, add=add)
+    later = ops.DeferredSums()
+    got = [ops.layernorm_bwd(dy, x, gamma, mean, rstd, add=add, defer=later) for _ in range(3)]
+    assert len(later.jobs) == 3
+    later.flush()
+    for dx, dg, db in got:
+        assert torch.equal(dx, want[0]) and torch.equal(dg, want[1]) and torch.equal(db, want[2])

@@ -352,8 +352,8 @@ __global__ __launch_bounds__(256) void token_reduce_kernel(const T* __restrict__
   }
 }
 
-__global__ __launch_bounds__(256) void partial_sum2_kernel(const float* __restrict__ partials, int nparts, int C,
-                                                           float* out0, float* out1) {
+__device__ __forceinline__ void partial_sum2_body(const float* __restrict__ partials, int nparts, int C,
+                                                  float* out0, float* out1) {
   __shared__ double red[2][64][4];
   const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;
   const int c = blockIdx.x * 4 + cl;
@@ -376,6 +376,22 @@ __global__ __launch_bounds__(256) void partial_sum2_kernel(const float* __restri
     if (out0) out0[cc] = (float)ss;
     if (out1) out1[cc] = (float)qq;
   }
+}
+
+__global__ __launch_bounds__(256) void partial_sum2_kernel(const float* __restrict__ partials, int nparts, int C,
+                                                           float* out0, float* out1) {
+  partial_sum2_body(partials, nparts, C, out0, out1);
+}
+
+// Many of those sums in one launch (the parameter gradients of every LayerNorm of a backward pass, taken at its
+// end): blockIdx.y = job, five int64 per job = partials, rows, C, out0, out1 (0 = not wanted).  Same arithmetic,
+// same bits as one launch per job.
+__global__ __launch_bounds__(256) void partial_sum2_batched_kernel(const long* __restrict__ jobs) {
+  const long* j = jobs + 5L * blockIdx.y;
+  const int C = (int)j[2];
+  if ((int)blockIdx.x * 4 >= C) return;
+  partial_sum2_body(reinterpret_cast<const float*>(j[0]), (int)j[1], C, reinterpret_cast<float*>(j[3]),
+                    reinterpret_cast<float*>(j[4]));
 }
 
 // ------------------------------------------------------------------ elementwise
@@ -938,10 +954,46 @@ int unetk_layernorm_fwd(const void* x, void* y, const float* gamma, const float*
 
 int unetk_token_reduce_num_partials(int64_t ntok) { return tok_blocks(ntok); }
 
+/* Rows of partials that unetk_layernorm_bwd_partials writes for this shape; 0 when the shape takes the two-pass
+ * form, which has no such split. */
+int unetk_layernorm_bwd_rows(int64_t ntok, int C, int dtype) {
+  if ((dtype != UNETK_F32 && dtype != UNETK_BF16) || ntok <= 0 || C <= 0 || C % VEC_OF(dtype) != 0) return 0;
+  if (ln_group(C / VEC_OF(dtype)) == 0) return 0;
+  const int nb = tok_blocks(ntok);
+  return (int)cdiv(ntok, cdiv(ntok, nb));
+}
+
+static int layernorm_bwd_impl(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                              const void* add, void* dx, float* dgamma, float* dbeta, float* partials, int64_t ntok,
+                              int C, int dtype, bool partials_only, hipStream_t stream);
+
 /* dx = LN'(dy) + add;  dgamma, dbeta = sums over tokens.  partials: [num_partials][2][C] */
 int unetk_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                         const void* add, void* dx, float* dgamma, float* dbeta, float* partials, int64_t ntok,
                         int C, int dtype, hipStream_t stream) {
+  return layernorm_bwd_impl(dy, x, gamma, mean, rstd, add, dx, dgamma, dbeta, partials, ntok, C, dtype, false, stream);
+}
+
+/* The first half only: dx, and unetk_layernorm_bwd_rows(ntok, C, dtype) rows of partials [row][2][C] whose column
+ * sums are dgamma and dbeta (unetk_partial_sums_batched adds them up, for many layers in one launch). */
+int unetk_layernorm_bwd_partials(const void* dy, const void* x, const float* gamma, const float* mean,
+                                 const float* rstd, const void* add, void* dx, float* partials, int64_t ntok, int C,
+                                 int dtype, hipStream_t stream) {
+  UNETK_CHECK_ARG(unetk_layernorm_bwd_rows(ntok, C, dtype) > 0, "layernorm_bwd_partials: no one-pass form for C=%d", C);
+  return layernorm_bwd_impl(dy, x, gamma, mean, rstd, add, dx, nullptr, nullptr, partials, ntok, C, dtype, true, stream);
+}
+
+int unetk_partial_sums_batched(const int64_t* jobs, int njobs, int max_C, hipStream_t stream) {
+  UNETK_CHECK_ARG(jobs && njobs > 0 && njobs <= 65535 && max_C > 0, "partial_sums_batched: bad arguments");
+  hipLaunchKernelGGL(partial_sum2_batched_kernel, dim3(cdiv(max_C, 4), njobs), dim3(256), 0, stream,
+                     reinterpret_cast<const long*>(jobs));
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+static int layernorm_bwd_impl(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                              const void* add, void* dx, float* dgamma, float* dbeta, float* partials, int64_t ntok,
+                              int C, int dtype, bool partials_only, hipStream_t stream) {
   UNETK_CHECK_ARG(dy && x && gamma && mean && rstd && dx && partials && ntok > 0, "layernorm_bwd: bad arguments");
   CHECK_DT("layernorm_bwd", dtype);
   UNETK_CHECK_ARG(C % VEC_OF(dtype) == 0, "layernorm_bwd: unsupported C=%d", C);
@@ -955,7 +1007,7 @@ int unetk_layernorm_bwd(const void* dy, const void* x, const float* gamma, const
 #define LN_BWD(G_, V_)                                                                                         \
   DISPATCH_T(dtype, hipLaunchKernelGGL((layernorm_bwd_group_kernel<T, G_, V_>), dim3(cdiv(ntok, chunk)), dim3(256), \
                                        0, stream, (const T*)dy, (const T*)x, gamma, mean, rstd, (const T*)add,   \
-                                       (T*)dx, (long)ntok, C, chunk, want_sums ? partials : nullptr))
+                                       (T*)dx, (long)ntok, C, chunk, (want_sums || partials_only) ? partials : nullptr))
     if (G == 16) LN_BWD(16, 1);
     else if (G == 32) LN_BWD(32, 1);
     else if (V == 1) LN_BWD(64, 1);

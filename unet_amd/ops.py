@@ -559,12 +559,55 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, add=None, need_param_grads=True):
-    """Returns (dx [+ add], dgamma, dbeta)."""
+class DeferredSums:
+    """Column sums of partial tables, taken later by one launch (the dgamma / dbeta of every LayerNorm of a
+    backward pass: two dozen 8-microsecond launches otherwise).  The outputs exist from the start; they hold
+    their values once flush() has run, in stream order."""
+
+    _TABLES = {}      # device -> (key, device table, pinned host copy): the last job table, re-used while nothing moved
+
+    def __init__(self):
+        self.jobs = []       # (partials, rows, C, out0, out1)
+
+    def add(self, partials, rows, C, out0, out1):
+        self.jobs.append((partials, rows, C, out0, out1))
+
+    def flush(self):
+        if not self.jobs:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("DeferredSums.flush() under HIP graph capture: its job table is uploaded from host "
+                               "memory, which a replayed graph would read again after it has been released")
+        dev = self.jobs[0][0].device
+        key = tuple(v for p, r, C, o0, o1 in self.jobs
+                    for v in (p.data_ptr(), r, C, o0.data_ptr() if o0 is not None else 0,
+                              o1.data_ptr() if o1 is not None else 0))
+        hit = DeferredSums._TABLES.get(dev)
+        if hit is None or hit[0] != key:
+            host = torch.tensor(key, dtype=torch.int64).pin_memory()
+            hit = (key, host.to(dev, non_blocking=True), host)
+            DeferredSums._TABLES[dev] = hit
+        call("unetk_partial_sums_batched", ptr(hit[1]), len(self.jobs), max(j[2] for j in self.jobs), stream())
+        self.jobs = []
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, add=None, need_param_grads=True, defer=None):
+    """Returns (dx [+ add], dgamma, dbeta).  defer: a DeferredSums that takes the two sums later (the returned
+    dgamma / dbeta are filled by its flush())."""
     C = x.shape[-1]
     ntok = x.numel() // C
     dev = x.device
     dx = torch.empty_like(x)
+    if defer is not None and need_param_grads:
+        rows = _lib.load().unetk_layernorm_bwd_rows(ntok, C, dtype_code(x.dtype))
+        if rows > 0:
+            partials = torch.empty((rows, 2, C), dtype=torch.float32, device=dev)
+            dg = torch.empty(C, dtype=torch.float32, device=dev)
+            db = torch.empty(C, dtype=torch.float32, device=dev)
+            call("unetk_layernorm_bwd_partials", ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(add), ptr(dx),
+                 ptr(partials), ntok, C, dtype_code(x.dtype), stream())
+            defer.add(partials, rows, C, dg, db)
+            return dx, dg, db
     nparts = _lib.load().unetk_token_reduce_num_partials(ntok)
     partials = torch.empty((nparts, 2, C), dtype=torch.float32, device=dev)
     dg = torch.empty(C, dtype=torch.float32, device=dev) if need_param_grads else None

@@ -206,13 +206,14 @@ class _Ctx:
     for training the data-gradient form) and looked up by the parameter's address; anything not
     found there (a reshaped copy) is packed on the spot.  Owned by the autograd node of the step
     (or dropped after an inference call): interleaved models or steps cannot see each other's packs."""
-    __slots__ = ("dt", "pool", "side", "held", "tracked")
+    __slots__ = ("dt", "pool", "side", "held", "tracked", "sums")
 
     def __init__(self, model, training):
         self.dt = dt = model.compute_dtype
         self.side = None        # set by the backward pass: the stream the weight gradients run on
         self.held = []
         self.tracked = []       # BatchNorm step counters of this forward: advanced by one launch at its end
+        self.sums = None        # set by the backward pass: the LayerNorm parameter-gradient sums taken at its end
         ws = []
         for m in model.modules():
             if isinstance(m, (nn.Linear, nn.Conv2d)):
@@ -245,6 +246,7 @@ class _Ctx:
 # chain leaves idle at every kernel's ramp-up and tail.  Off with a data-parallel gradient sink
 # (the sink copies each gradient on the main stream as soon as it is produced).
 OVERLAP_WGRAD = os.environ.get("UNETK_SWIN_OVERLAP_WGRAD", "1") != "0"
+DEFER_LN_SUMS = os.environ.get("UNETK_SWIN_DEFER_LN_SUMS", "1") != "0"     # LayerNorm dgamma / dbeta sums: one launch at the end of the backward
 _SIDE_STREAMS = {}
 
 
@@ -369,7 +371,7 @@ def _block_bwd(blk, pre, ctx, dx2, cx, grads):
         dhp = ops.gelu_bwd(dh, hpre)
     dln2 = _linear_bwd(ln2, dhp, blk.mlp[0].weight, cx, grads, pre + "mlp.0.weight", pre + "mlp.0.bias")
     dx1, grads[pre + "norm2.weight"], grads[pre + "norm2.bias"] = ops.layernorm_bwd(
-        dln2, x1, blk.norm2.weight, m2, r2, add=dx2)
+        dln2, x1, blk.norm2.weight, m2, r2, add=dx2, defer=cx.sums)
     # attention branch
     db = ops.scale_sample(dx1, keep1) if keep1 is not None else dx1
     dbp = _pad_tokens(db, He, We) if padded else db
@@ -380,7 +382,7 @@ def _block_bwd(blk, pre, ctx, dx2, cx, grads):
     if padded:
         dln1 = dln1[:, :H, :W].contiguous()
     dx, grads[pre + "norm1.weight"], grads[pre + "norm1.bias"] = ops.layernorm_bwd(
-        dln1, x, blk.norm1.weight, m1, r1, add=dx1)
+        dln1, x, blk.norm1.weight, m1, r1, add=dx1, defer=cx.sums)
     return dx
 
 
@@ -537,6 +539,11 @@ class _SwinTrainFn(torch.autograd.Function):
         grads = ops.GradOut(model.grad_sink)
         main = torch.cuda.current_stream()
         cx.side = _side_stream(dout.device) if (OVERLAP_WGRAD and model.grad_sink is None) else None
+        # dgamma / dbeta of the 25 LayerNorms: their partial tables are summed by one launch at the end (a gradient
+        # sink wants every gradient complete the moment it is handed over: then each sum runs in place)
+        # (not while a HIP graph is being captured: the job table would be uploaded from host memory inside the graph)
+        cx.sums = ops.DeferredSums() if (DEFER_LN_SUMS and model.grad_sink is None and
+                                         not torch.cuda.is_current_stream_capturing()) else None
         nl = model.num_layers
         dskips: Dict[int, torch.Tensor] = {}
         g = None
@@ -564,7 +571,7 @@ class _SwinTrainFn(torch.autograd.Function):
                 _, ds, pre, li, (shape, mg, mm, rr, ln) = rec
                 dln = _linear_bwd(ln, g, ds.reduction.weight, cx, grads, pre + "reduction.weight", None)
                 dmg, grads[pre + "norm.weight"], grads[pre + "norm.bias"] = ops.layernorm_bwd(
-                    dln, mg, ds.norm.weight, mm, rr)
+                    dln, mg, ds.norm.weight, mm, rr, defer=cx.sums)
                 g = ops.merge_scatter(dmg, shape[1], shape[2])
                 if li in dskips:       # the stage output also feeds a decoder skip
                     g = ops.scale_sample(g, None, dskips.pop(li))
@@ -575,7 +582,7 @@ class _SwinTrainFn(torch.autograd.Function):
                 tok_in, t0, m0, r0 = rec[1]
                 E = model.embed_dim_val
                 dt0, grads["norm_embed.weight"], grads["norm_embed.bias"] = ops.layernorm_bwd(
-                    g, t0, model.norm_embed.weight, m0, r0)
+                    g, t0, model.norm_embed.weight, m0, r0, defer=cx.sums)
                 wpe = model.patch_embed.weight.reshape(E, -1)
                 K = wpe.shape[1]
                 grads["patch_embed.weight"] = ops.conv_wgrad(tok_in, dt0, K, E, 1).view(model.patch_embed.weight.shape)
@@ -585,6 +592,9 @@ class _SwinTrainFn(torch.autograd.Function):
                     dtok = _linear_launch(dt0, cx.packed(wpe, transpose=True))
                     B, Cin, H, W = ctx.in_shape
                     g = ops.unpatchify(dtok, Cin, H, W, model.patch_size_val)
+        if cx.sums is not None:
+            cx.sums.flush()
+            cx.sums = None
         if cx.side is not None:
             main.wait_stream(cx.side)
             cx.side = None
