@@ -310,6 +310,11 @@ int unetk_window_attn_fwd(const void* qkv, void* out, const float* table, int B,
 int unetk_window_attn_bwd(const void* qkv, const void* dout, void* dqkv, const float* table, float* dtable,
                           float* dtable_partials, int B, int He, int We, int C, int heads, int shift, int use_mask,
                           float scale, int dtype, unetk_stream_t stream);
+/* dtable_partials: [B * nW * heads][225].  dtable may be null: then the partials are summed later, for every
+ * attention layer of the backward pass (:206-219, one table per block) by one launch of
+ * unetk_dtable_reduce_batched: jobs (device) = four int64 per job: partials, B * nW, heads, dtable;
+ * max_heads = the largest head count among them.  Same bits as the in-place sum. */
+int unetk_dtable_reduce_batched(const int64_t* jobs, int njobs, int max_heads, unetk_stream_t stream);
 
 /* ---- optimizer tail: clip_grad_norm_ + AdamW over a list of fp32 tensors ----------------
  * enhanced_training_multi_loss.py:758-763 (AdamW), :827-829 (clip_grad_norm_(1.0), step);

@@ -441,3 +441,23 @@ def test_layernorm_backward_deferred_sums_same_bits(C, ntok):
     later.flush()
     for dx, dg, db in got:
         assert torch.equal(dx, want[0]) and torch.equal(dg, want[1]) and torch.equal(db, want[2])
+
+
+def test_bias_table_gradient_deferred_sum_same_bits():
+    """Window-attention backward with the relative-position table gradient summed later, for several layers by one
+    launch, against the in-place sum: the same dqkv and the same table gradient, bit for bit."""
+    from unet_amd import ops
+    g = torch.Generator().manual_seed(11)
+    later = ops.DeferredSums()
+    want, got = [], []
+    for B, H, W, heads, shift in ((2, 16, 16, 3, 0), (1, 8, 8, 12, 4), (3, 16, 8, 6, 4)):
+        C = heads * 32
+        qkv = torch.randn(B, H, W, 3 * C, generator=g).cuda().to(torch.bfloat16)
+        dout = torch.randn(B, H, W, C, generator=g).cuda().to(torch.bfloat16)
+        table = (torch.randn(225, heads, generator=g) * 0.02).cuda()
+        want.append(ops.window_attn_bwd(qkv, dout, table, heads, shift, True))
+        got.append(ops.window_attn_bwd(qkv, dout, table, heads, shift, True, defer=later))
+    assert len(later.tables) == 3
+    later.flush()
+    for (dq0, dt0), (dq1, dt1) in zip(want, got):
+        assert torch.equal(dq0, dq1) and torch.equal(dt0, dt1)

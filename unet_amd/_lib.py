@@ -108,6 +108,7 @@ _SIGNATURES = {
     "unetk_convt2x2_fwd": (I, [P, I, P, P, I, I, I, I, I, I, I, I, P, P]),
     "unetk_window_attn_fwd": (I, [P, P, P, I, I, I, I, I, I, I, F, I, P]),
     "unetk_window_attn_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, F, I, P]),
+    "unetk_dtable_reduce_batched": (I, [P, I, I, P]),
 }
 
 _lib = None

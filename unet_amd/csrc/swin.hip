@@ -880,13 +880,25 @@ __global__ __launch_bounds__(64) void window_attn_bwd_kernel(const T* __restrict
 }
 
 // dtable[bin][head] = sum over (b, window) of the partials, fixed order
-__global__ __launch_bounds__(64) void dtable_reduce_kernel(const float* __restrict__ partials, int nwin, int heads,
-                                                           float* __restrict__ dtable) {
+__device__ __forceinline__ void dtable_reduce_body(const float* __restrict__ partials, int nwin, int heads,
+                                                   float* __restrict__ dtable) {
   const int bin = blockIdx.x, head = blockIdx.y;
   float s = 0.f;
   for (int w = threadIdx.x; w < nwin; w += 64) s += partials[((long)w * heads + head) * 225 + bin];
   s = wave_sum(s);
   if (threadIdx.x == 0) dtable[bin * heads + head] = s;
+}
+__global__ __launch_bounds__(64) void dtable_reduce_kernel(const float* __restrict__ partials, int nwin, int heads,
+                                                           float* __restrict__ dtable) {
+  dtable_reduce_body(partials, nwin, heads, dtable);
+}
+// The same for every attention layer of a backward pass in one launch: blockIdx.z = job, four int64 per job =
+// partials, windows (B * nW), heads, dtable.
+__global__ __launch_bounds__(64) void dtable_reduce_batched_kernel(const long* __restrict__ jobs) {
+  const long* j = jobs + 4L * blockIdx.z;
+  const int heads = (int)j[2];
+  if ((int)blockIdx.y >= heads) return;
+  dtable_reduce_body(reinterpret_cast<const float*>(j[0]), (int)j[1], heads, reinterpret_cast<float*>(j[3]));
 }
 
 // channels per workgroup slab: the largest divisor split of C with at most 256 vector groups
@@ -1183,8 +1195,7 @@ int unetk_window_attn_fwd(const void* qkv, void* out, const float* table, int B,
 int unetk_window_attn_bwd(const void* qkv, const void* dout, void* dqkv, const float* table, float* dtable,
                           float* dtable_partials, int B, int He, int We, int C, int heads, int shift, int use_mask,
                           float scale, int dtype, hipStream_t stream) {
-  UNETK_CHECK_ARG(qkv && dout && dqkv && table && dtable && dtable_partials && B > 0,
-                  "window_attn_bwd: bad arguments");
+  UNETK_CHECK_ARG(qkv && dout && dqkv && table && dtable_partials && B > 0, "window_attn_bwd: bad arguments");
   CHECK_DT("window_attn_bwd", dtype);
   if (int rc = check_attn("window_attn_bwd", He, We, C, heads, shift)) return rc;
   AttnGeom g{B, He, We, C, heads, shift, use_mask, scale};
@@ -1197,8 +1208,19 @@ int unetk_window_attn_bwd(const void* qkv, const void* dout, void* dqkv, const f
                        (const float*)dout, (float*)dqkv, table, dtable_partials, g);
     UNETK_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(dtable_reduce_kernel, dim3(225, heads), dim3(64), 0, stream, dtable_partials, nwin, heads,
-                     dtable);
+  if (dtable != nullptr) {      // (null: the caller sums the partials later, unetk_dtable_reduce_batched)
+    hipLaunchKernelGGL(dtable_reduce_kernel, dim3(225, heads), dim3(64), 0, stream, dtable_partials, nwin, heads,
+                       dtable);
+    UNETK_CHECK_LAUNCH();
+  }
+  return UNETK_OK;
+}
+
+int unetk_dtable_reduce_batched(const int64_t* jobs, int njobs, int max_heads, hipStream_t stream) {
+  UNETK_CHECK_ARG(jobs && njobs > 0 && njobs <= 65535 && max_heads > 0 && max_heads <= 65535,
+                  "dtable_reduce_batched: bad arguments");
+  hipLaunchKernelGGL(dtable_reduce_batched_kernel, dim3(225, max_heads, njobs), dim3(64), 0, stream,
+                     reinterpret_cast<const long*>(jobs));
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }

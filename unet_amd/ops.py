@@ -564,31 +564,46 @@ class DeferredSums:
     backward pass: two dozen 8-microsecond launches otherwise).  The outputs exist from the start; they hold
     their values once flush() has run, in stream order."""
 
-    _TABLES = {}      # device -> (key, device table, pinned host copy): the last job table, re-used while nothing moved
+    _TABLES = {}      # (device, kind) -> (key, device table, pinned host copy): the last job table, re-used while nothing moved
 
     def __init__(self):
-        self.jobs = []       # (partials, rows, C, out0, out1)
+        self.jobs = []       # (partials, rows, C, out0, out1): column sums of [rows][2][C] tables
+        self.tables = []     # (partials, windows, heads, dtable): relative-position bias table gradients
 
     def add(self, partials, rows, C, out0, out1):
         self.jobs.append((partials, rows, C, out0, out1))
 
+    def add_table(self, partials, nwin, heads, dtable):
+        self.tables.append((partials, nwin, heads, dtable))
+
+    @staticmethod
+    def _upload(dev, kind, key):
+        hit = DeferredSums._TABLES.get((dev, kind))
+        if hit is None or hit[0] != key:
+            host = torch.tensor(key, dtype=torch.int64).pin_memory()
+            hit = (key, host.to(dev, non_blocking=True), host)
+            DeferredSums._TABLES[(dev, kind)] = hit
+        return hit[1]
+
     def flush(self):
-        if not self.jobs:
+        if not self.jobs and not self.tables:
             return
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("DeferredSums.flush() under HIP graph capture: its job table is uploaded from host "
                                "memory, which a replayed graph would read again after it has been released")
-        dev = self.jobs[0][0].device
-        key = tuple(v for p, r, C, o0, o1 in self.jobs
-                    for v in (p.data_ptr(), r, C, o0.data_ptr() if o0 is not None else 0,
-                              o1.data_ptr() if o1 is not None else 0))
-        hit = DeferredSums._TABLES.get(dev)
-        if hit is None or hit[0] != key:
-            host = torch.tensor(key, dtype=torch.int64).pin_memory()
-            hit = (key, host.to(dev, non_blocking=True), host)
-            DeferredSums._TABLES[dev] = hit
-        call("unetk_partial_sums_batched", ptr(hit[1]), len(self.jobs), max(j[2] for j in self.jobs), stream())
-        self.jobs = []
+        if self.jobs:
+            dev = self.jobs[0][0].device
+            key = tuple(v for p, r, C, o0, o1 in self.jobs
+                        for v in (p.data_ptr(), r, C, o0.data_ptr() if o0 is not None else 0,
+                                  o1.data_ptr() if o1 is not None else 0))
+            call("unetk_partial_sums_batched", ptr(self._upload(dev, "sums", key)), len(self.jobs),
+                 max(j[2] for j in self.jobs), stream())
+        if self.tables:
+            dev = self.tables[0][0].device
+            key = tuple(v for p, n, h, t in self.tables for v in (p.data_ptr(), n, h, t.data_ptr()))
+            call("unetk_dtable_reduce_batched", ptr(self._upload(dev, "tables", key)), len(self.tables),
+                 max(j[2] for j in self.tables), stream())
+        self.jobs, self.tables = [], []
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, add=None, need_param_grads=True, defer=None):
@@ -697,8 +712,8 @@ def window_attn_fwd(qkv, table, heads, shift, use_mask):
     return out
 
 
-def window_attn_bwd(qkv, dout, table, heads, shift, use_mask):
-    """Returns (dqkv, dtable (225, heads))."""
+def window_attn_bwd(qkv, dout, table, heads, shift, use_mask, defer=None):
+    """Returns (dqkv, dtable (225, heads)).  defer: a DeferredSums that sums the table's partials later."""
     B, He, We, C3 = qkv.shape
     C = C3 // 3
     dev = qkv.device
@@ -706,6 +721,9 @@ def window_attn_bwd(qkv, dout, table, heads, shift, use_mask):
     nblk = B * (He // 8) * (We // 8) * heads
     partials = torch.empty((nblk, 225), dtype=torch.float32, device=dev)
     dtable = torch.empty((225, heads), dtype=torch.float32, device=dev)
-    call("unetk_window_attn_bwd", ptr(qkv), ptr(dout), ptr(dqkv), ptr(table), ptr(dtable), ptr(partials), B, He,
-         We, C, heads, shift, 1 if use_mask else 0, (C // heads) ** -0.5, dtype_code(qkv.dtype), stream())
+    call("unetk_window_attn_bwd", ptr(qkv), ptr(dout), ptr(dqkv), ptr(table), None if defer is not None else ptr(dtable),
+         ptr(partials), B, He, We, C, heads, shift, 1 if use_mask else 0, (C // heads) ** -0.5, dtype_code(qkv.dtype),
+         stream())
+    if defer is not None:
+        defer.add_table(partials, nblk // heads, heads, dtable)
     return dqkv, dtable

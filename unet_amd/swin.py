@@ -377,7 +377,7 @@ def _block_bwd(blk, pre, ctx, dx2, cx, grads):
     dbp = _pad_tokens(db, He, We) if padded else db
     datt = _linear_bwd(att, dbp, a.proj.weight, cx, grads, pre + "attn.proj.weight", pre + "attn.proj.bias")
     dqkv, grads[pre + "attn.relative_position_bias_table"] = ops.window_attn_bwd(
-        qkv, datt, a.relative_position_bias_table, a.num_heads, blk.shift_size, True)
+        qkv, datt, a.relative_position_bias_table, a.num_heads, blk.shift_size, True, defer=cx.sums)
     dln1 = _linear_bwd(ln1p, dqkv, a.qkv.weight, cx, grads, pre + "attn.qkv.weight", pre + "attn.qkv.bias")
     if padded:
         dln1 = dln1[:, :H, :W].contiguous()
