@@ -268,11 +268,14 @@ int unetk_layernorm_bwd(const void* dy, const void* x, const float* gamma, const
  * unetk_layernorm_bwd_partials writes dx and unetk_layernorm_bwd_rows(ntok, C, dtype) rows of partials
  * [row][2][C] (0 rows: the shape has no one-pass form, use unetk_layernorm_bwd);
  * unetk_partial_sums_batched sums njobs such tables: jobs (device) = five int64 per job: partials, rows, C,
- * dgamma, dbeta (0 = not wanted); max_C = the largest C among them.  Same bits as unetk_layernorm_bwd. */
+ * dgamma, dbeta (0 = not wanted); max_C = the largest C among them.  Same bits as unetk_layernorm_bwd.
+ * dx_scaled (nullable): a second output, dx * keep[token / tok_per_sample] - the DropPath factor (:139-148) of the
+ * branch whose backward reads this gradient next (same bits as unetk_scale_sample applied to dx). */
 int unetk_layernorm_bwd_rows(int64_t ntok, int C, int dtype);
 int unetk_layernorm_bwd_partials(const void* dy, const void* x, const float* gamma, const float* mean,
                                  const float* rstd, const void* add, void* dx, float* partials, int64_t ntok, int C,
-                                 int dtype, unetk_stream_t stream);
+                                 int dtype, const float* keep, int64_t tok_per_sample, void* dx_scaled,
+                                 unetk_stream_t stream);
 int unetk_partial_sums_batched(const int64_t* jobs, int njobs, int max_C, unetk_stream_t stream);
 /* bias gradients of the linears: out[c] = sum over tokens */
 int unetk_channel_sum(const void* x, int ld, int64_t ntok, int C, float* out, float* partials, int dtype,

@@ -438,6 +438,12 @@ def test_layernorm_backward_deferred_sums_same_bits(C, ntok):
     later = ops.DeferredSums()
     got = [ops.layernorm_bwd(dy, x, gamma, mean, rstd, add=add, defer=later) for _ in range(3)]
     assert len(later.jobs) == 3
+    # ... and with the DropPath scaling of the next branch as a second output (4 samples, some dropped)
+    keep = torch.tensor([0.0, 1 / 0.9, 1 / 0.9, 0.0]).cuda() if ntok % 4 == 0 else None
+    if keep is not None:
+        dx, dg, db, dxs = ops.layernorm_bwd(dy, x, gamma, mean, rstd, add=add, defer=later, scale_next=(keep, ntok // 4))
+        got.append((dx, dg, db))
+        assert torch.equal(dxs.view(torch.int16), ops.scale_sample(dx.view(4, ntok // 4, C), keep).view(1, ntok, C).view(torch.int16))
     later.flush()
     for dx, dg, db in got:
         assert torch.equal(dx, want[0]) and torch.equal(dg, want[1]) and torch.equal(db, want[2])

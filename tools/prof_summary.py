@@ -4,6 +4,7 @@
     python tools/prof_summary.py <kernel_stats.csv> <out.csv> "<title>" <steps>
 """
 import csv
+import os
 import re
 import sys
 
@@ -28,7 +29,7 @@ def main():
     rows = list(csv.DictReader(open(src)))
     tot = sum(float(r['TotalDurationNs']) for r in rows)
     out = [f"# {title}", "kernel,calls,total_ms,avg_us,percent,ms_per_step"]
-    for r in rows[:32]:
+    for r in rows[:(400 if os.environ.get("PROF_ALL") else 32)]:      # PROF_ALL=1: every kernel, not the top 32
         t = float(r['TotalDurationNs'])
         out.append(f"{short(r['Name'])},{r['Calls']},{t/1e6:.3f},{float(r['AverageNs'])/1e3:.1f},"
                    f"{t/tot*100:.2f},{t/1e6/steps:.3f}")

@@ -95,7 +95,7 @@ _SIGNATURES = {
     "unetk_token_reduce_num_partials": (I, [L]),
     "unetk_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, L, I, I, P]),
     "unetk_layernorm_bwd_rows": (I, [L, I, I]),
-    "unetk_layernorm_bwd_partials": (I, [P, P, P, P, P, P, P, P, L, I, I, P]),
+    "unetk_layernorm_bwd_partials": (I, [P, P, P, P, P, P, P, P, L, I, I, P, L, P, P]),
     "unetk_partial_sums_batched": (I, [P, I, I, P]),
     "unetk_channel_sum": (I, [P, I, L, I, P, P, I, P]),
     "unetk_gelu_fwd": (I, [P, P, L, I, P]),

@@ -207,7 +207,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_group_kernel(const T* __res
                                                                   const float* __restrict__ rstd,
                                                                   const T* __restrict__ add, T* __restrict__ dx,
                                                                   long ntok, int C, int chunk,
-                                                                  float* __restrict__ partials) {
+                                                                  float* __restrict__ partials,
+                                                                  const float* __restrict__ keep, long tok_per_sample,
+                                                                  T* __restrict__ dxs) {
+  // dxs (optional): dx as stored, times the per-sample DropPath factor keep[token / tok_per_sample] of the branch
+  // that consumes it next - what scale_sample_kernel would compute from dx in a pass of its own, same bits
   constexpr int E = Vec16<T>::N;
   constexpr int TPW = 256 / G;
   __shared__ float red[2][256 * E];
@@ -249,6 +253,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_group_kernel(const T* __res
     s1 = group_sum<G>(s1) / (float)C;
     s2 = group_sum<G>(s2) / (float)C;
     if (live) {
+      const float kf = dxs != nullptr ? keep[tok / tok_per_sample] : 1.f;
 #pragma unroll
       for (int k = 0; k < V; ++k) {
         const int cg = k * G + gl;
@@ -263,6 +268,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_group_kernel(const T* __res
             o.v[e] = from_f32<T>(rs * (g - s1 - xh * s2) + (add ? to_f32(av.v[e]) : 0.f));
           }
           store16(dx + tok * C + cg * E, o);
+          if (dxs != nullptr) {
+            Vec16<T> os;
+#pragma unroll
+            for (int e = 0; e < E; ++e) os.v[e] = from_f32<T>(to_f32(o.v[e]) * kf + 0.f);
+            store16(dxs + tok * C + cg * E, os);
+          }
         }
       }
     }
@@ -977,22 +988,28 @@ int unetk_layernorm_bwd_rows(int64_t ntok, int C, int dtype) {
 
 static int layernorm_bwd_impl(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                               const void* add, void* dx, float* dgamma, float* dbeta, float* partials, int64_t ntok,
-                              int C, int dtype, bool partials_only, hipStream_t stream);
+                              int C, int dtype, bool partials_only, const float* keep, int64_t tok_per_sample,
+                              void* dx_scaled, hipStream_t stream);
 
 /* dx = LN'(dy) + add;  dgamma, dbeta = sums over tokens.  partials: [num_partials][2][C] */
 int unetk_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                         const void* add, void* dx, float* dgamma, float* dbeta, float* partials, int64_t ntok,
                         int C, int dtype, hipStream_t stream) {
-  return layernorm_bwd_impl(dy, x, gamma, mean, rstd, add, dx, dgamma, dbeta, partials, ntok, C, dtype, false, stream);
+  return layernorm_bwd_impl(dy, x, gamma, mean, rstd, add, dx, dgamma, dbeta, partials, ntok, C, dtype, false, nullptr, 1,
+                            nullptr, stream);
 }
 
 /* The first half only: dx, and unetk_layernorm_bwd_rows(ntok, C, dtype) rows of partials [row][2][C] whose column
  * sums are dgamma and dbeta (unetk_partial_sums_batched adds them up, for many layers in one launch). */
 int unetk_layernorm_bwd_partials(const void* dy, const void* x, const float* gamma, const float* mean,
                                  const float* rstd, const void* add, void* dx, float* partials, int64_t ntok, int C,
-                                 int dtype, hipStream_t stream) {
+                                 int dtype, const float* keep, int64_t tok_per_sample, void* dx_scaled,
+                                 hipStream_t stream) {
   UNETK_CHECK_ARG(unetk_layernorm_bwd_rows(ntok, C, dtype) > 0, "layernorm_bwd_partials: no one-pass form for C=%d", C);
-  return layernorm_bwd_impl(dy, x, gamma, mean, rstd, add, dx, nullptr, nullptr, partials, ntok, C, dtype, true, stream);
+  UNETK_CHECK_ARG(dx_scaled == nullptr || (keep != nullptr && tok_per_sample > 0 && ntok % tok_per_sample == 0),
+                  "layernorm_bwd_partials: the scaled copy needs the per-sample factors and whole samples");
+  return layernorm_bwd_impl(dy, x, gamma, mean, rstd, add, dx, nullptr, nullptr, partials, ntok, C, dtype, true, keep,
+                            tok_per_sample > 0 ? tok_per_sample : 1, dx_scaled, stream);
 }
 
 int unetk_partial_sums_batched(const int64_t* jobs, int njobs, int max_C, hipStream_t stream) {
@@ -1005,7 +1022,8 @@ int unetk_partial_sums_batched(const int64_t* jobs, int njobs, int max_C, hipStr
 
 static int layernorm_bwd_impl(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                               const void* add, void* dx, float* dgamma, float* dbeta, float* partials, int64_t ntok,
-                              int C, int dtype, bool partials_only, hipStream_t stream) {
+                              int C, int dtype, bool partials_only, const float* keep, int64_t tok_per_sample,
+                              void* dx_scaled, hipStream_t stream) {
   UNETK_CHECK_ARG(dy && x && gamma && mean && rstd && dx && partials && ntok > 0, "layernorm_bwd: bad arguments");
   CHECK_DT("layernorm_bwd", dtype);
   UNETK_CHECK_ARG(C % VEC_OF(dtype) == 0, "layernorm_bwd: unsupported C=%d", C);
@@ -1019,7 +1037,8 @@ static int layernorm_bwd_impl(const void* dy, const void* x, const float* gamma,
 #define LN_BWD(G_, V_)                                                                                         \
   DISPATCH_T(dtype, hipLaunchKernelGGL((layernorm_bwd_group_kernel<T, G_, V_>), dim3(cdiv(ntok, chunk)), dim3(256), \
                                        0, stream, (const T*)dy, (const T*)x, gamma, mean, rstd, (const T*)add,   \
-                                       (T*)dx, (long)ntok, C, chunk, (want_sums || partials_only) ? partials : nullptr))
+                                       (T*)dx, (long)ntok, C, chunk, (want_sums || partials_only) ? partials : nullptr, \
+                                       keep, (long)tok_per_sample, (T*)dx_scaled))
     if (G == 16) LN_BWD(16, 1);
     else if (G == 32) LN_BWD(32, 1);
     else if (V == 1) LN_BWD(64, 1);

@@ -606,9 +606,11 @@ class DeferredSums:
         self.jobs, self.tables = [], []
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, add=None, need_param_grads=True, defer=None):
+def layernorm_bwd(dy, x, gamma, mean, rstd, add=None, need_param_grads=True, defer=None, scale_next=None):
     """Returns (dx [+ add], dgamma, dbeta).  defer: a DeferredSums that takes the two sums later (the returned
-    dgamma / dbeta are filled by its flush())."""
+    dgamma / dbeta are filled by its flush()).  scale_next = (keep (B,) fp32, tokens per sample), with defer only:
+    a fourth result, dx times the per-sample factor (scale_sample(dx, keep) without its launch), or None when the
+    shape has no one-pass form."""
     C = x.shape[-1]
     ntok = x.numel() // C
     dev = x.device
@@ -619,17 +621,19 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, add=None, need_param_grads=True, def
             partials = torch.empty((rows, 2, C), dtype=torch.float32, device=dev)
             dg = torch.empty(C, dtype=torch.float32, device=dev)
             db = torch.empty(C, dtype=torch.float32, device=dev)
+            dxs = torch.empty_like(x) if scale_next is not None else None
             call("unetk_layernorm_bwd_partials", ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(add), ptr(dx),
-                 ptr(partials), ntok, C, dtype_code(x.dtype), stream())
+                 ptr(partials), ntok, C, dtype_code(x.dtype), ptr(scale_next[0]) if scale_next is not None else None,
+                 scale_next[1] if scale_next is not None else 0, ptr(dxs), stream())
             defer.add(partials, rows, C, dg, db)
-            return dx, dg, db
+            return (dx, dg, db) if scale_next is None else (dx, dg, db, dxs)
     nparts = _lib.load().unetk_token_reduce_num_partials(ntok)
     partials = torch.empty((nparts, 2, C), dtype=torch.float32, device=dev)
     dg = torch.empty(C, dtype=torch.float32, device=dev) if need_param_grads else None
     db = torch.empty(C, dtype=torch.float32, device=dev) if need_param_grads else None
     call("unetk_layernorm_bwd", ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(add), ptr(dx), ptr(dg),
          ptr(db), ptr(partials), ntok, C, dtype_code(x.dtype), stream())
-    return dx, dg, db
+    return (dx, dg, db) if scale_next is None else (dx, dg, db, None)
 
 
 def channel_sum(x, C=None):

@@ -364,12 +364,21 @@ def _block_fwd(blk, pre, x, keep1, keep2, cx, save):
     return x2
 
 
-def _block_bwd(blk, pre, ctx, dx2, cx, grads):
+def _block_bwd(blk, pre, ctx, dx2, cx, grads, db2=None, keep_next=None):
+    """dx2: gradient of the block's output; db2: the same times this block's second DropPath factors when the
+    producer of dx2 wrote it (else formed here); keep_next: the second DropPath factors of the block whose
+    backward runs next.  Returns (dx, dx times keep_next or None)."""
     x, m1, r1, ln1p, qkv, att, x1, m2, r2, ln2, hpre, hact, keep1, keep2, (H, W, He, We) = ctx
     a = blk.attn
     padded = (He, We) != (H, W)
+    # the DropPath scaling of a gradient is a second output of the LayerNorm backward that produces it
+    # (one launch less per branch), where that backward runs in its one-pass form
+    fuse = cx.sums is not None and not padded
     # MLP branch
-    db = ops.scale_sample(dx2, keep2) if keep2 is not None else dx2
+    if db2 is not None:
+        db = db2
+    else:
+        db = ops.scale_sample(dx2, keep2) if keep2 is not None else dx2
     # d hidden = (d out @ W2) * GELU'(pre-activation): inside the GEMM's epilogue where the hidden tensor is
     # large (it saves one write and one read of it); on the small late stages the separate pass is as fast
     if hpre.numel() >= _FUSE_GELU_BWD_ELEMS:
@@ -379,10 +388,14 @@ def _block_bwd(blk, pre, ctx, dx2, cx, grads):
         dh = _linear_bwd(hact, db, blk.mlp[3].weight, cx, grads, pre + "mlp.3.weight", pre + "mlp.3.bias")
         dhp = ops.gelu_bwd(dh, hpre)
     dln2 = _linear_bwd(ln2, dhp, blk.mlp[0].weight, cx, grads, pre + "mlp.0.weight", pre + "mlp.0.bias")
-    dx1, grads[pre + "norm2.weight"], grads[pre + "norm2.bias"] = ops.layernorm_bwd(
-        dln2, x1, blk.norm2.weight, m2, r2, add=dx2, defer=cx.sums)
+    res = ops.layernorm_bwd(dln2, x1, blk.norm2.weight, m2, r2, add=dx2, defer=cx.sums,
+                            scale_next=(keep1, H * W) if (fuse and keep1 is not None) else None)
+    dx1, grads[pre + "norm2.weight"], grads[pre + "norm2.bias"] = res[:3]
     # attention branch
-    db = ops.scale_sample(dx1, keep1) if keep1 is not None else dx1
+    if len(res) == 4 and res[3] is not None:
+        db = res[3]
+    else:
+        db = ops.scale_sample(dx1, keep1) if keep1 is not None else dx1
     dbp = _pad_tokens(db, He, We) if padded else db
     datt = _linear_bwd(att, dbp, a.proj.weight, cx, grads, pre + "attn.proj.weight", pre + "attn.proj.bias")
     dqkv, grads[pre + "attn.relative_position_bias_table"] = ops.window_attn_bwd(
@@ -390,9 +403,10 @@ def _block_bwd(blk, pre, ctx, dx2, cx, grads):
     dln1 = _linear_bwd(ln1p, dqkv, a.qkv.weight, cx, grads, pre + "attn.qkv.weight", pre + "attn.qkv.bias")
     if padded:
         dln1 = dln1[:, :H, :W].contiguous()
-    dx, grads[pre + "norm1.weight"], grads[pre + "norm1.bias"] = ops.layernorm_bwd(
-        dln1, x, blk.norm1.weight, m1, r1, add=dx1, defer=cx.sums)
-    return dx
+    res = ops.layernorm_bwd(dln1, x, blk.norm1.weight, m1, r1, add=dx1, defer=cx.sums,
+                            scale_next=(keep_next, H * W) if (fuse and keep_next is not None) else None)
+    dx, grads[pre + "norm1.weight"], grads[pre + "norm1.bias"] = res[:3]
+    return dx, (res[3] if len(res) == 4 else None)
 
 
 def _conv_bn_relu_fwd(conv, bn, t, cx, training, save, tag):
@@ -557,8 +571,12 @@ class _SwinTrainFn(torch.autograd.Function):
         dskips: Dict[int, torch.Tensor] = {}
         g = None
         pending_skip = None
-        for rec in reversed(save):
+        g_scaled = None                  # g times the next block's DropPath factors, when its producer wrote it
+        for ri in range(len(save) - 1, -1, -1):
+            rec = save[ri]
             kind = rec[0]
+            if kind != "block":
+                g_scaled = None
             if kind == "packs":
                 continue
             if kind == "head":
@@ -586,7 +604,11 @@ class _SwinTrainFn(torch.autograd.Function):
                     g = ops.scale_sample(g, None, dskips.pop(li))
             elif kind == "block":
                 _, blk, pre, c = rec
-                g = _block_bwd(blk, pre, c, g, cx, grads)
+                # the block that runs next (the previous one of the same stage) gets its scaled gradient with g
+                nxt = save[ri - 1] if ri > 0 else None
+                keep_next = nxt[3][13] if (nxt is not None and nxt[0] == "block" and nxt[3][14] == c[14]) else None
+                g, g_scaled = _block_bwd(blk, pre, c, g, cx, grads, db2=g_scaled, keep_next=keep_next)
+                continue
             elif kind == "embed":
                 tok_in, t0, m0, r0 = rec[1]
                 E = model.embed_dim_val
