@@ -52,3 +52,15 @@ for _ in range(10):
     host += time.perf_counter() - h0
 torch.cuda.synchronize()
 print(f"host time to queue one step on an idle GPU: {host / 10 * 1e3:.2f} ms")
+
+if os.environ.get("HOST_PROFILE"):
+    import cProfile, pstats
+    torch.cuda.synchronize()
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(5):
+        step()
+    pr.disable()
+    torch.cuda.synchronize()
+    st = pstats.Stats(pr)
+    st.sort_stats("tottime").print_stats(28)

@@ -156,7 +156,16 @@ def ptr(t):
     return c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+_SLOW_STREAM = os.environ.get("UNETK_STREAM_VIA_TORCH") == "1"       # A/B switch: the Stream-object route
+
+
 def stream():
+    """The current HIP stream of the current device as a ctypes pointer.  Every kernel launch asks for it: the
+    raw accessors take well under a microsecond, torch.cuda.current_stream() builds a Stream object (~9)."""
+    if _raw_stream is not None and _raw_device is not None and not _SLOW_STREAM:
+        return c_void_p(_raw_stream(_raw_device()))
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -203,9 +203,18 @@ class SwinUNet(nn.Module):
             return torch.zeros((x.shape[0], 1, x.shape[2], x.shape[3]), device=x.device, dtype=x.dtype)
         if self.training:
             dp = self._draw_drop_path(x.shape[0], x.device)
-            return _SwinTrainFn.apply(x, self, dp, *list(self.parameters()))
+            return _SwinTrainFn.apply(x, self, dp, *[p for _, p in _named_params(self)])
         with torch.no_grad():
             return _forward(self, x, None, None)
+
+
+def _named_params(model):
+    """list(model.named_parameters()), kept on the model: the walk over the module tree costs the host ~0.5 ms and
+    runs twice per step; the set of parameters of a built model does not change."""
+    hit = model.__dict__.get("_named_params_list")
+    if hit is None:
+        hit = model.__dict__["_named_params_list"] = list(model.named_parameters())
+    return hit
 
 
 # ------------------------------------------------------------------ packed weights
@@ -223,13 +232,17 @@ class _Ctx:
         self.held = []
         self.tracked = []       # BatchNorm step counters of this forward: advanced by one launch at its end
         self.sums = None        # set by the backward pass: the LayerNorm parameter-gradient sums taken at its end
+        # (the walk over the module tree costs the host ~1 ms: its result is kept on the model, which does not
+        # grow layers between steps; what can change - device, dtype, layout of a weight - is checked every time)
+        cand = model.__dict__.get("_packable_modules")
+        if cand is None:
+            cand = model.__dict__["_packable_modules"] = [m for m in model.modules() if isinstance(m, (nn.Linear, nn.Conv2d))]
         ws = []
-        for m in model.modules():
-            if isinstance(m, (nn.Linear, nn.Conv2d)):
-                w = m.weight
-                if w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and \
-                        (w.dim() == 2 or (w.shape[2] == w.shape[3] and w.shape[2] in (1, 3))):
-                    ws.append(w)
+        for m in cand:
+            w = m.weight
+            if w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and \
+                    (w.dim() == 2 or (w.shape[2] == w.shape[3] and w.shape[2] in (1, 3))):
+                ws.append(w)
         forms = (False, True) if training else (False,)
         packs = ops.pack_many([(w, tr) for tr in forms for w in ws], dt)
         self.pool = {}
@@ -631,5 +644,5 @@ class _SwinTrainFn(torch.autograd.Function):
             cx.side = None
         cx.held.clear()
         ctx.save = None
-        outg = [grads.get(n) if p.requires_grad else None for n, p in model.named_parameters()]
+        outg = [grads.get(n) if p.requires_grad else None for n, p in _named_params(model)]
         return (g if ctx.need_dx else None, None, None, *outg)
