@@ -47,7 +47,9 @@ int64_t unetk_conv_packed_elems(int Co, int Ci, int ks, int bn, int dtype);
 int unetk_conv_pack_weight(const float* w, void* packed, int Co, int Ci, int ks, int bn, int dtype,
                            int transpose, unetk_stream_t stream);
 /* Many weights in one launch.  jobs (device): 9 int64 per job = fp32 source pointer, destination
- * offset in elements from dst_base (16-byte aligned), Co, Ci, ks, bn, ceil(packed Ci / channels-per-chunk), transpose, packed
+ * offset in elements from dst_base (16-byte aligned), Co, Ci, ks, bn, ceil(packed Ci / channels-per-chunk), transpose
+ * (+2: the source is a ConvTranspose2d(k=2, s=2) weight [Ci][Co/4][2][2], swin_unet_model.py:501, taken as the
+ * matrix [(ky*2+kx)*Co/4 + co][ci] that unetk_convt2x2_fwd multiplies by; ks = 1), packed
  * element count (unetk_conv_packed_elems); Co/Ci are the SOURCE tensor's.  blocks (device): per
  * workgroup two int32 = (job, group inside the job); nblocks of them.  A job has
  * unetk_conv_pack_groups(packed Co, packed Ci, ks, bn, dtype) groups (packed = swapped when transpose=1),

@@ -461,3 +461,21 @@ def test_batched_weight_packing_matches_single_packs(dt):
         assert (pk.bn, pk.Co, pk.Ci, pk.ks) == (one.bn, one.Co, one.Ci, one.ks)
         assert torch.equal(pk.data.view(torch.uint8), one.data.view(torch.uint8)), (tuple(w.shape), tr)
         assert torch.equal(pk2.data.view(torch.uint8), one.data.view(torch.uint8)), (tuple(w.shape), tr)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_batched_packing_of_conv_transpose_weights(dt):
+    """A ConvTranspose2d(k=2, s=2) weight packed by the batched launch as its (4*up, Cin) GEMM matrix, forward and
+    data-gradient form, against the pack of the permuted copy: the same bits."""
+    from unet_amd import ops
+    g = torch.Generator().manual_seed(9)
+    for Cin, up in ((768, 384), (128, 64), (40, 24), (96, 8)):
+        w = torch.randn(Cin, up, 2, 2, generator=g).cuda()
+        lin = torch.randn(up, Cin, generator=g).cuda()                   # an ordinary weight in the same launch
+        w2 = w.permute(2, 3, 1, 0).reshape(4 * up, Cin).contiguous()
+        got = ops.pack_many([(lin, False), (w, "convt"), (w, "convt_t"), (lin, True)], dt)
+        want = [ops.PackedConv(lin, dt), ops.PackedConv(w2, dt), ops.PackedConv(w2, dt, transpose=True),
+                ops.PackedConv(lin, dt, transpose=True)]
+        for a, b in zip(got, want):
+            assert (a.bn, a.Co, a.Ci, a.ks) == (b.bn, b.Co, b.Ci, b.ks)
+            assert torch.equal(a.data.view(torch.uint8), b.data.view(torch.uint8)), (Cin, up)

@@ -1500,7 +1500,13 @@ __device__ __forceinline__ int small_div(int e, float inv) { return (int)(((floa
 
 template <typename T, int TAPS>
 __device__ __forceinline__ void pack_group(const float* __restrict__ w, T* __restrict__ dst, float* buf, int Co, int Ci,
-                                           int bn, int nchunks, int transpose, int g) {
+                                           int bn, int nchunks, int transpose, int convt, int g) {
+  // convt (1x1 jobs only): the source is a ConvTranspose2d(k=2, s=2) weight [Ci][up][2][2] read as the matrix
+  // W[(ky*2+kx)*up + co][ci] of the GEMM that computes the four output pixels of an input pixel (Co = 4*up)
+  const int up = Co >> 2;
+  auto at = [&](int a, int b) -> float {       // element (row a, column b) of the Co x Ci source matrix
+    return convt ? w[((long)b * up + (a % up)) * 4 + a / up] : w[(long)a * Ci + b];
+  };
   constexpr int KC = MMA<T>::KC;
   const int RG = TAPS == 1 ? bn : 16, gpb = bn / RG;
   const int rg = g % gpb, ch = (g / gpb) % nchunks, nb = g / (gpb * nchunks);
@@ -1509,7 +1515,7 @@ __device__ __forceinline__ void pack_group(const float* __restrict__ w, T* __res
   const int tid = threadIdx.x;
   // 1x1 weights whose rows start on 16-byte boundaries move as float4 (four times fewer load instructions: the
   // loads, not the bytes, bound this kernel); the 36-byte taps of a 3x3 weight keep no such alignment
-  const bool vec = TAPS == 1 && (Ci & 3) == 0 && ((uintptr_t)w & 15) == 0;
+  const bool vec = TAPS == 1 && !convt && (Ci & 3) == 0 && ((uintptr_t)w & 15) == 0;
   if (!transpose) {
     constexpr int RUN = KC * TAPS;           // floats of one source row that belong to the chunk
     if (vec) {
@@ -1524,7 +1530,7 @@ __device__ __forceinline__ void pack_group(const float* __restrict__ w, T* __res
       for (int e = tid; e < RG * RUN; e += 256) {
         const int r = e / RUN, q = e % RUN;
         const int n = n0 + r, c = c0 + q / TAPS;
-        buf[e] = (n < Co && c < Ci) ? w[((long)n * Ci + c0) * TAPS + q] : 0.f;
+        buf[e] = (n < Co && c < Ci) ? (TAPS == 1 ? at(n, c) : w[((long)n * Ci + c0) * TAPS + q]) : 0.f;
       }
     }
   } else {
@@ -1544,7 +1550,7 @@ __device__ __forceinline__ void pack_group(const float* __restrict__ w, T* __res
       for (int e = tid; e < KC * run; e += 256) {
         const int k = small_div(e, inv), q = e - k * run;
         const int c = c0 + k, n = n0 + q / TAPS;
-        buf[k * pitch + q] = (c < Co && n < Ci) ? w[((long)c * Ci + n0) * TAPS + q] : 0.f;
+        buf[k * pitch + q] = (c < Co && n < Ci) ? (TAPS == 1 ? at(c, n) : w[((long)c * Ci + n0) * TAPS + q]) : 0.f;
       }
     }
   }
@@ -1575,9 +1581,10 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const long* _
   const long* j = jobs + 9L * job;
   const float* __restrict__ w = reinterpret_cast<const float*>(j[0]);
   T* __restrict__ dst = dst_base + j[1];
-  const int Co = (int)j[2], Ci = (int)j[3], ks = (int)j[4], bn = (int)j[5], nchunks = (int)j[6], transpose = (int)j[7];
-  if (ks == 1) pack_group<T, 1>(w, dst, buf, Co, Ci, bn, nchunks, transpose, g);
-  else         pack_group<T, 9>(w, dst, buf, Co, Ci, bn, nchunks, transpose, g);
+  const int Co = (int)j[2], Ci = (int)j[3], ks = (int)j[4], bn = (int)j[5], nchunks = (int)j[6];
+  const int transpose = (int)j[7] & 1, convt = ((int)j[7] >> 1) & 1;
+  if (ks == 1) pack_group<T, 1>(w, dst, buf, Co, Ci, bn, nchunks, transpose, convt, g);
+  else         pack_group<T, 9>(w, dst, buf, Co, Ci, bn, nchunks, transpose, 0, g);
 }
 
 // up to 48 -> 48 channels, bf16, 3x3 (the full-resolution layers): the persistent whole-pixel kernel (it has

@@ -99,9 +99,11 @@ _PACK_TABLES = {}      # (pointers, shapes) -> (jobs, blocks, nblocks, pinned ho
 
 def pack_many(weights, dt):
     """Pack several weights with ONE launch.  weights: list of (fp32 GPU tensor (Co, Ci[, k, k]), transpose);
-    returns the list of PackedConv (views of one buffer).  The device-side job table depends on the
-    source addresses and shapes only, and parameters do not move: a training step re-uses it (a new
-    one goes up from pinned memory without blocking the host)."""
+    returns the list of PackedConv (views of one buffer).  transpose may also be "convt" / "convt_t": the tensor is
+    a ConvTranspose2d(k=2, s=2) weight (Cin, up, 2, 2), packed as the (4*up, Cin) matrix whose row
+    (ky*2+kx)*up + co is weight[:, co, ky, kx] (forward form) or as its data-gradient form.  The device-side job
+    table depends on the source addresses and shapes only, and parameters do not move: a training step re-uses it
+    (a new one goes up from pinned memory without blocking the host)."""
     if not weights:
         return []
     import numpy as np
@@ -118,18 +120,26 @@ def pack_many(weights, dt):
     metas, srcs, rows, off = [], [], [], 0
     for w, transpose in weights:
         _require_cuda(w, "weight")
-        if w.dim() == 2:
+        convt = isinstance(transpose, str)
+        if convt:
+            if transpose not in ("convt", "convt_t") or w.dim() != 4 or tuple(w.shape[2:]) != (2, 2):
+                raise ValueError("pack_many: the ConvTranspose form takes a (Cin, up, 2, 2) weight")
+            transpose = transpose == "convt_t"
+        elif w.dim() == 2:
             w = w.view(w.shape[0], w.shape[1], 1, 1)
         w = w.detach()
         if w.dtype != torch.float32 or not w.is_contiguous():
             w = w.contiguous().float()
-        Co, Ci, ks, _ = w.shape
+        if convt:
+            Co, Ci, ks = 4 * w.shape[1], w.shape[0], 1
+        else:
+            Co, Ci, ks, _ = w.shape
         pCo, pCi = (Ci, Co) if transpose else (Co, Ci)
         bn = lib.unetk_conv_pick_bn(pCo)
         n = lib.unetk_conv_packed_elems(pCo, pCi, ks, bn, dtype_code(dt))
         metas.append((pCo, pCi, ks, bn, off, n))
         srcs.append(w)
-        rows.append((w.data_ptr(), off, Co, Ci, ks, bn, -(-pCi // kc), 1 if transpose else 0, n))
+        rows.append((w.data_ptr(), off, Co, Ci, ks, bn, -(-pCi // kc), (1 if transpose else 0) + (2 if convt else 0), n))
         off += -(-n // 8) * 8                     # keep every pack 16-byte aligned
     dev = srcs[0].device
     key = (tuple(rows), dt, dev)

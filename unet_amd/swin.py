@@ -237,19 +237,41 @@ class _Ctx:
         cand = model.__dict__.get("_packable_modules")
         if cand is None:
             cand = model.__dict__["_packable_modules"] = [m for m in model.modules() if isinstance(m, (nn.Linear, nn.Conv2d))]
+            model.__dict__["_convt_modules"] = [m for m in model.modules() if isinstance(m, nn.ConvTranspose2d) and
+                                                tuple(m.kernel_size) == (2, 2) and tuple(m.stride) == (2, 2)]
         ws = []
         for m in cand:
             w = m.weight
             if w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and \
                     (w.dim() == 2 or (w.shape[2] == w.shape[3] and w.shape[2] in (1, 3))):
                 ws.append(w)
+        # the ConvTranspose2d(k=2, s=2) weights of the decoder go into the same launch, as the GEMM matrices they
+        # are used as (else: a permuted copy and a pack of its own per decoder block, forward and backward)
+        wt = [m.weight for m in model.__dict__.get("_convt_modules", ())
+              if m.weight.is_cuda and m.weight.dtype == torch.float32 and m.weight.is_contiguous()]
         forms = (False, True) if training else (False,)
-        packs = ops.pack_many([(w, tr) for tr in forms for w in ws], dt)
+        packs = ops.pack_many([(w, tr) for tr in forms for w in ws] +
+                              [(w, "convt_t" if tr else "convt") for tr in forms for w in wt], dt)
         self.pool = {}
         for i, tr in enumerate(forms):
             for j, w in enumerate(ws):
                 self.pool[(w.data_ptr(), tr)] = (packs[i * len(ws) + j], w.shape[0], w.shape[1],
                                                  1 if w.dim() == 2 else w.shape[2], w._version)
+            for j, w in enumerate(wt):
+                self.pool[(w.data_ptr(), tr, "convt")] = (packs[len(forms) * len(ws) + i * len(wt) + j], w._version)
+
+    def packed_convt(self, w, transpose=False):
+        """The pack of a ConvTranspose2d(k=2, s=2) weight (Cin, up, 2, 2) as its (4*up, Cin) GEMM matrix (or that
+        matrix's data-gradient form), from the step's one launch when it is there."""
+        hit = self.pool.get((w.data_ptr(), bool(transpose), "convt"))
+        if hit is not None:
+            if hit[1] != w._version:
+                raise RuntimeError("a SwinUNet parameter was modified in place between the forward pass and its "
+                                   "backward pass (the packed copies made by the forward no longer match)")
+            return hit[0]
+        up, Cin = w.shape[1], w.shape[0]
+        w2 = w.permute(2, 3, 1, 0).reshape(4 * up, Cin)       # [(ky,kx,co)][ci]
+        return ops.PackedConv(w2, self.dt, transpose=transpose)
 
     def packed(self, w, transpose=False):
         hit = self.pool.get((w.data_ptr(), bool(transpose)))
@@ -460,8 +482,7 @@ def _decoder_fwd(dec, pre, x, skip, cx, training, save):
     up = dec.upsample.out_channels
     has_skip = skip is not None and dec.skip_projection is not None
     cat = torch.empty((B, 2 * h, 2 * w, up * (2 if has_skip else 1)), dtype=cx.dt, device=x.device)
-    w2 = dec.upsample.weight.permute(2, 3, 1, 0).reshape(4 * up, Cin)       # [(ky,kx,co)][ci]
-    pk2 = cx.packed(w2)
+    pk2 = cx.packed_convt(dec.upsample.weight)      # the (4*up, Cin) matrix [(ky,kx,co)][ci]
     if ops.linear_supported(x, pk2) and up % 8 == 0 and x.is_contiguous():
         ops.convT2x2_fwd(x, pk2, dec.upsample.bias, cat)          # the pixel shuffle is the GEMM's store address
     else:
@@ -476,7 +497,7 @@ def _decoder_fwd(dec, pre, x, skip, cx, training, save):
             resized = sp.shape[1:3]
             cat[..., up:] = ops.upsample_concat(sp, torch.empty((B, 2 * h, 2 * w, 0), dtype=cx.dt, device=x.device))
     if save is not None:
-        save.append(("dec_head", dec, pre, (x, skip, w2, resized)))
+        save.append(("dec_head", dec, pre, (x, skip, None, resized)))
     t = _conv_bn_relu_fwd(dec.conv_block[0], dec.conv_block[1], cat, cx, training, save,
                           (pre + "conv_block.0", pre + "conv_block.1"))
     return _conv_bn_relu_fwd(dec.conv_block[3], dec.conv_block[4], t, cx, training, save,
@@ -485,7 +506,7 @@ def _decoder_fwd(dec, pre, x, skip, cx, training, save):
 
 def _decoder_head_bwd(dec, pre, ctx, dcat, cx, grads):
     """Returns (dx, dskip or None)."""
-    x, skip, w2, resized = ctx
+    x, skip, _, resized = ctx
     B, h, w, Cin = x.shape
     up = dec.upsample.out_channels
     dtmp = torch.empty((B, h, w, 4 * up), dtype=cx.dt, device=x.device)
@@ -494,7 +515,7 @@ def _decoder_head_bwd(dec, pre, ctx, dcat, cx, grads):
     grads[pre + "upsample.weight"] = _on_side(
         cx, lambda: ops.linear_wgrad(x, dtmp, Cin, 4 * up, want_bias=False)[0].view(2, 2, up, Cin)
         .permute(3, 2, 0, 1).contiguous(), x, dtmp)
-    dx = _linear_launch(dtmp, ops.PackedConv(w2.contiguous(), cx.dt, transpose=True))
+    dx = _linear_launch(dtmp, cx.packed_convt(dec.upsample.weight, transpose=True))
     dskip = None
     if skip is not None and dec.skip_projection is not None:
         wsk = dec.skip_projection.weight
