@@ -307,6 +307,12 @@ int unetk_pixel_shuffle(void* tmp, void* cat, int ldcat, const float* bias, int 
  * e.g. the first half of the decoder's concat buffer).  bfloat16; shapes as unetk_linear_supported(B*h*w, K, 4*up, bn). */
 int unetk_convt2x2_fwd(const void* x, int ldx, const void* wpacked, void* out, int ldo, int B, int h, int w, int K,
                        int up, int bn, int dtype, const float* bias, unetk_stream_t stream);
+/* Its data gradient in one launch: dx[b][y][x][:] = sum over (ky, kx, co) of dout[b][2y+ky][2x+kx][co] * W, a GEMM
+ * with K = 4 * up whose operand rows are gathered from the gradient image dout (B, 2h, 2w, lddo >= up) - the inverse
+ * pixel shuffle is the operand's load address.  wpackedT: the data-gradient pack of the (4 * up, N) matrix
+ * (unetk_conv_pack_weights, transpose + ConvTranspose form); up a multiple of 32; dx (B, h, w, ldo >= N). */
+int unetk_convt2x2_bwd_data(const void* dout, int lddo, const void* wpackedT, void* dx, int ldo, int B, int h, int w,
+                            int up, int N, int bn, int dtype, unetk_stream_t stream);
 /* WindowAttention + cyclic shift + window partition/reverse (:161-200, 241-269, 339-360), window 8,
  * head dim 32.  qkv: (B,He,We,3C) from the qkv linear; out: (B,He,We,C) before the proj linear.
  * table: relative_position_bias_table (225, heads) fp32. */

@@ -467,3 +467,30 @@ def test_bias_table_gradient_deferred_sum_same_bits():
     later.flush()
     for (dq0, dt0), (dq1, dt1) in zip(want, got):
         assert torch.equal(dq0, dq1) and torch.equal(dt0, dt1)
+
+
+@pytest.mark.parametrize("B,h,w,Cin,up,extra", [(2, 8, 8, 768, 384, 384), (1, 16, 12, 128, 64, 0), (3, 5, 7, 256, 128, 128),
+                                                (1, 64, 64, 128, 64, 64)])
+def test_conv_transpose_data_gradient_gathers_its_operand(B, h, w, Cin, up, extra):
+    """The ConvTranspose2d(k=2, s=2) data gradient as one GEMM that reads the gradient image in place, against the
+    un-shuffle into a token matrix followed by the plain GEMM (the same products in the same order: same bits) and
+    against torch's conv_transpose2d backward."""
+    from unet_amd import ops
+    g = torch.Generator().manual_seed(B * h + Cin)
+    dt = torch.bfloat16
+    wt = (torch.randn(Cin, up, 2, 2, generator=g) * 0.05)
+    dcat = torch.randn(B, 2 * h, 2 * w, up + extra, generator=g).to(dt)
+    w2 = wt.permute(2, 3, 1, 0).reshape(4 * up, Cin).contiguous().cuda()
+    pkT = ops.PackedConv(w2, dt, transpose=True)
+    dc = dcat.cuda()
+    got = ops.convT2x2_bwd_data(dc, up, pkT, h, w)
+    assert got is not None
+    dtmp = torch.empty((B, h, w, 4 * up), dtype=dt, device="cuda")
+    ops.pixel_shuffle(dtmp, dc, None, up, backward=True)
+    want = ops.linear_fwd(dtmp, pkT)
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    x = torch.zeros(B, Cin, h, w, requires_grad=True)
+    y = F.conv_transpose2d(x, wt.to(dt).float(), stride=2)
+    y.backward(dcat[..., :up].float().permute(0, 3, 1, 2))
+    ref = x.grad.permute(0, 2, 3, 1)
+    assert ((got.float().cpu() - ref).norm() / ref.norm()).item() < 1e-2

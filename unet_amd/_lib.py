@@ -106,6 +106,7 @@ _SIGNATURES = {
     "unetk_merge_gather": (I, [P, P, I, I, I, I, I, I, P]),
     "unetk_pixel_shuffle": (I, [P, P, I, P, I, I, I, I, I, I, P]),
     "unetk_convt2x2_fwd": (I, [P, I, P, P, I, I, I, I, I, I, I, I, P, P]),
+    "unetk_convt2x2_bwd_data": (I, [P, I, P, P, I, I, I, I, I, I, I, I, P]),
     "unetk_window_attn_fwd": (I, [P, P, P, I, I, I, I, I, I, I, F, I, P]),
     "unetk_window_attn_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, F, I, P]),
     "unetk_dtable_reduce_batched": (I, [P, I, I, P]),

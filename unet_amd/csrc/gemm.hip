@@ -57,6 +57,10 @@ struct GemmArgs {
   // ConvTranspose2d(k=2, s=2) as a GEMM with N = 4 * up: channel n = (ky, kx, co) of token (b, y, x) is channel co
   // of output pixel (b, 2y + ky, 2x + kx).  shuf_up = 0: a plain [M][ldo] result.
   int shuf_up, shuf_w, shuf_hw;
+  // The data gradient of that layer is the GEMM with K = 4 * gin_up whose operand row of token (b, y, x) is gathered
+  // from the gradient image: channels (ky, kx, co) = channel co of pixel (b, 2y + ky, 2x + kx) of x [B][2h][2w][ldx]
+  // (a 32-channel chunk lies inside one (ky, kx): gin_up is a multiple of 32).  gin_up = 0: plain [M][ldx] rows.
+  int gin_up, gin_w, gin_hw;
   int mtiles, nby, tiles_per_xcd;
 };
 
@@ -128,8 +132,20 @@ __global__ __launch_bounds__(256) void lin_gemm_kernel(GemmArgs a) {
     const int i = wave + 4 * k;
     const int row = 16 * i + (lane >> 2);
     const int slot = (lane & 3) ^ swz(row);
-    asrc[k] = (i < APIECES && m0 + row < a.M) ? a.x + (long)(m0 + row) * a.ldx + slot * 8 : nullptr;
+    long first = (long)(m0 + row) * a.ldx;          // element offset of the token's row
+    if (a.gin_up) {                                  // ... or of pixel (b, 2y, 2x) of the gradient image
+      const int t = m0 + row, bb = t / a.gin_hw, rem = t - bb * a.gin_hw, y = rem / a.gin_w, x = rem - y * a.gin_w;
+      first = (((long)bb * 4 * a.gin_hw) + (long)(2 * y) * (2 * a.gin_w) + 2 * x) * a.ldx;
+    }
+    asrc[k] = (i < APIECES && m0 + row < a.M) ? a.x + first + slot * 8 : nullptr;
   }
+  // element offset of chunk ch inside the token's row (plain: ch * 32)
+  const int gin_cpq = a.gin_up ? a.gin_up / 32 : 1;
+  auto chunk_off = [&](int ch) -> long {
+    if (!a.gin_up) return (long)ch * 32;
+    const int qd = ch / gin_cpq, c0 = (ch - qd * gin_cpq) * 32;
+    return ((long)(qd >> 1) * (2 * a.gin_w) + (qd & 1)) * a.ldx + c0;
+  };
   const bf16* wbase = a.w + (long)nb * a.nchunks * BN * 32;
   int woff[WPW];
 #pragma unroll
@@ -139,10 +155,11 @@ __global__ __launch_bounds__(256) void lin_gemm_kernel(GemmArgs a) {
   }
   auto issue = [&](int ch) {
     char* dst = lds + (ch % NSTAGE) * STAGE;
+    const long coff = chunk_off(ch);
 #pragma unroll
     for (int k = 0; k < APW; ++k) {
       const int i = wave + 4 * k;
-      if (i < APIECES) glds16g(asrc[k] != nullptr ? asrc[k] + ch * 32 : zero, dst + i * 1024);
+      if (i < APIECES) glds16g(asrc[k] != nullptr ? asrc[k] + coff : zero, dst + i * 1024);
     }
     const bf16* ws = wbase + (long)ch * BN * 32;
 #pragma unroll
@@ -885,6 +902,7 @@ int unetk_linear_fwd(const void* x, int ldx, const void* wpacked, void* out, int
   a.M = (int)M; a.N = N; a.K = K; a.nchunks = K / 32; a.act = act;
   a.tok_per_sample = resid_keep ? (int)tok_per_sample : 1;
   a.shuf_up = a.shuf_w = a.shuf_hw = 0;
+  a.gin_up = a.gin_w = a.gin_hw = 0;
   // 128-token tiles, three workgroups per CU.  (256-token tiles, two per CU, measured slower on every
   // Swin shape, 64x64 tokens x 96 channels to 8x8 tokens x 3072 channels: these products are bound by
   // bytes and by how many workgroups cover each other's waits, not by the MFMA : LDS-read ratio.)
@@ -911,6 +929,32 @@ int unetk_convt2x2_fwd(const void* x, int ldx, const void* wpacked, void* out, i
   a.ldx = ldx; a.ldo = ldo; a.ldo2 = 0; a.ldr = 0; a.ldaux = 0;
   a.M = (int)M; a.N = N; a.K = K; a.nchunks = K / 32; a.act = UNETK_ACT_NONE; a.tok_per_sample = 1;
   a.shuf_up = up; a.shuf_w = w; a.shuf_hw = h * w;
+  a.gin_up = a.gin_w = a.gin_hw = 0;
+  switch (bn) {
+    case 96: return launch_gemm<2, 6>(a, stream);
+    case 64: return launch_gemm<2, 4>(a, stream);
+    default: return launch_gemm<2, 2>(a, stream);
+  }
+}
+
+int unetk_convt2x2_bwd_data(const void* dout, int lddo, const void* wpackedT, void* dx, int ldo, int B, int h, int w,
+                            int up, int N, int bn, int dtype, hipStream_t stream) {
+  UNETK_CHECK_ARG(dout && wpackedT && dx && B > 0 && h > 0 && w > 0 && up > 0 && N > 0, "convt2x2_bwd_data: bad arguments");
+  const int64_t M = (int64_t)B * h * w;
+  const int K = 4 * up;
+  UNETK_CHECK_ARG(unetk_linear_supported(M, K, N, bn, dtype) && up % 32 == 0 && 4 * M < (1LL << 31),
+                  "convt2x2_bwd_data: unsupported shape or type (B=%d h=%d w=%d up=%d N=%d block %d dtype %d): bfloat16, "
+                  "up a multiple of 32, N a multiple of its channel block", B, h, w, up, N, bn, dtype);
+  UNETK_CHECK_ARG(lddo >= up && ldo >= N && lddo % 8 == 0 && ldo % 8 == 0 && ((uintptr_t)dout % 16) == 0 &&
+                  ((uintptr_t)dx % 16) == 0 && ((uintptr_t)wpackedT % 16) == 0 && 4 * M * (int64_t)lddo < (1LL << 40),
+                  "convt2x2_bwd_data: bad strides or alignment");
+  GemmArgs a;
+  a.x = (const bf16*)dout; a.w = (const bf16*)wpackedT; a.out = (bf16*)dx; a.out2 = nullptr;
+  a.bias = nullptr; a.resid = nullptr; a.keep = nullptr; a.aux = nullptr;
+  a.ldx = lddo; a.ldo = ldo; a.ldo2 = 0; a.ldr = 0; a.ldaux = 0;
+  a.M = (int)M; a.N = N; a.K = K; a.nchunks = K / 32; a.act = UNETK_ACT_NONE; a.tok_per_sample = 1;
+  a.shuf_up = a.shuf_w = a.shuf_hw = 0;
+  a.gin_up = up; a.gin_w = w; a.gin_hw = h * w;
   switch (bn) {
     case 96: return launch_gemm<2, 6>(a, stream);
     case 64: return launch_gemm<2, 4>(a, stream);

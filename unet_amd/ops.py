@@ -268,6 +268,22 @@ def linear_fwd(x, pw: PackedConv, bias=None, act=0, resid=None, resid_keep=None,
     return (out, second) if out2 else out
 
 
+def convT2x2_bwd_data(dout, up, pwT, h, w):
+    """Data gradient of ConvTranspose2d(k=2, s=2): dout (B, 2h, 2w, >= up channels, the first ``up`` are read) ->
+    dx (B, h, w, Cin); pwT: the data-gradient pack of the (4*up, Cin) matrix.  None when the GEMM path does not take
+    the shape (the caller un-shuffles into a token matrix and runs the plain product)."""
+    B = dout.shape[0]
+    Cin = pwT.Co
+    if not (dout.dtype == torch.bfloat16 and up % 32 == 0 and pwT.Ci == 4 * up and dout.stride(3) == 1 and
+            dout.stride(1) == dout.shape[2] * dout.stride(2) and dout.stride(0) == dout.shape[1] * dout.stride(1) and
+            _lib.load().unetk_linear_supported(B * h * w, 4 * up, Cin, pwT.bn, dtype_code(dout.dtype))):
+        return None
+    dx = torch.empty((B, h, w, Cin), dtype=dout.dtype, device=dout.device)
+    call("unetk_convt2x2_bwd_data", ptr(dout), dout.stride(2), ptr(pwT.data), ptr(dx), Cin, B, h, w, up, Cin, pwT.bn,
+         dtype_code(dout.dtype), stream())
+    return dx
+
+
 def convT2x2_fwd(x, pw: PackedConv, bias, out):
     """ConvTranspose2d(k=2, s=2) + bias of channels-last x (B,h,w,K) into channels [0, up) of out (B,2h,2w,ld): one
     GEMM launch whose epilogue stores every value at its shuffled pixel.  pw: the pack of the (4*up, K) matrix with

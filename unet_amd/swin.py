@@ -291,6 +291,7 @@ class _Ctx:
 # (the sink copies each gradient on the main stream as soon as it is produced).
 OVERLAP_WGRAD = os.environ.get("UNETK_SWIN_OVERLAP_WGRAD", "1") != "0"
 DEFER_LN_SUMS = os.environ.get("UNETK_SWIN_DEFER_LN_SUMS", "1") != "0"     # LayerNorm dgamma / dbeta sums: one launch at the end of the backward
+CONVT_BWD_GATHER = os.environ.get("UNETK_SWIN_CONVT_BWD_GATHER", "1") != "0"   # ConvTranspose data gradient reads the gradient image in place
 _SIDE_STREAMS = {}
 
 
@@ -509,13 +510,25 @@ def _decoder_head_bwd(dec, pre, ctx, dcat, cx, grads):
     x, skip, _, resized = ctx
     B, h, w, Cin = x.shape
     up = dec.upsample.out_channels
-    dtmp = torch.empty((B, h, w, 4 * up), dtype=cx.dt, device=x.device)
-    ops.pixel_shuffle(dtmp, dcat, None, up, backward=True)
     grads[pre + "upsample.bias"] = ops.channel_sum(dcat, up)
-    grads[pre + "upsample.weight"] = _on_side(
-        cx, lambda: ops.linear_wgrad(x, dtmp, Cin, 4 * up, want_bias=False)[0].view(2, 2, up, Cin)
-        .permute(3, 2, 0, 1).contiguous(), x, dtmp)
-    dx = _linear_launch(dtmp, cx.packed_convt(dec.upsample.weight, transpose=True))
+    pkT = cx.packed_convt(dec.upsample.weight, transpose=True)
+    # the data gradient gathers its operand rows from dcat (the inverse pixel shuffle is the GEMM's load address);
+    # the un-shuffled token matrix is then only the weight gradient's operand, made on its stream
+    dx = ops.convT2x2_bwd_data(dcat, up, pkT, h, w) if CONVT_BWD_GATHER else None
+    if dx is not None:
+        def wjob():
+            dtmp = torch.empty((B, h, w, 4 * up), dtype=cx.dt, device=x.device)
+            ops.pixel_shuffle(dtmp, dcat, None, up, backward=True)
+            return ops.linear_wgrad(x, dtmp, Cin, 4 * up, want_bias=False)[0].view(2, 2, up, Cin) \
+                .permute(3, 2, 0, 1).contiguous()
+        grads[pre + "upsample.weight"] = _on_side(cx, wjob, x, dcat)
+    else:
+        dtmp = torch.empty((B, h, w, 4 * up), dtype=cx.dt, device=x.device)
+        ops.pixel_shuffle(dtmp, dcat, None, up, backward=True)
+        grads[pre + "upsample.weight"] = _on_side(
+            cx, lambda: ops.linear_wgrad(x, dtmp, Cin, 4 * up, want_bias=False)[0].view(2, 2, up, Cin)
+            .permute(3, 2, 0, 1).contiguous(), x, dtmp)
+        dx = _linear_launch(dtmp, pkT)
     dskip = None
     if skip is not None and dec.skip_projection is not None:
         wsk = dec.skip_projection.weight
