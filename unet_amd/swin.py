@@ -510,7 +510,7 @@ def _decoder_head_bwd(dec, pre, ctx, dcat, cx, grads):
     x, skip, _, resized = ctx
     B, h, w, Cin = x.shape
     up = dec.upsample.out_channels
-    grads[pre + "upsample.bias"] = ops.channel_sum(dcat, up)
+    grads[pre + "upsample.bias"] = _on_side(cx, lambda: ops.channel_sum(dcat, up), dcat)     # (a leaf: off the chain)
     pkT = cx.packed_convt(dec.upsample.weight, transpose=True)
     # the data gradient gathers its operand rows from dcat (the inverse pixel shuffle is the GEMM's load address);
     # the un-shuffled token matrix is then only the weight gradient's operand, made on its stream
@@ -664,7 +664,7 @@ class _SwinTrainFn(torch.autograd.Function):
                 wpe = model.patch_embed.weight.reshape(E, -1)
                 K = wpe.shape[1]
                 grads["patch_embed.weight"] = ops.conv_wgrad(tok_in, dt0, K, E, 1).view(model.patch_embed.weight.shape)
-                grads["patch_embed.bias"] = ops.channel_sum(dt0, E)
+                grads["patch_embed.bias"] = _on_side(cx, lambda: ops.channel_sum(dt0, E), dt0)
                 g = None
                 if ctx.need_dx:
                     dtok = _linear_launch(dt0, cx.packed(wpe, transpose=True))
