@@ -494,3 +494,33 @@ def test_conv_transpose_data_gradient_gathers_its_operand(B, h, w, Cin, up, extr
     y.backward(dcat[..., :up].float().permute(0, 3, 1, 2))
     ref = x.grad.permute(0, 2, 3, 1)
     assert ((got.float().cpu() - ref).norm() / ref.norm()).item() < 1e-2
+
+
+def test_new_entry_points_reject_bad_arguments():
+    """Host-side checks of the entry points added for the Swin backward: nothing is launched on a bad call."""
+    from unet_amd import ops
+    from unet_amd._lib import call, ptr, dtype_code, stream
+    dt = torch.bfloat16
+    x = torch.zeros(1, 8, 8, 96, device="cuda", dtype=dt)
+    stat = torch.zeros(64, device="cuda")
+    gamma = torch.ones(96, device="cuda")
+    part = torch.zeros(64, 2, 96, device="cuda")
+    with pytest.raises(ValueError):        # a scaled copy without the per-sample factors
+        call("unetk_layernorm_bwd_partials", ptr(x), ptr(x), ptr(gamma), ptr(stat), ptr(stat), None, ptr(x), ptr(part),
+             64, 96, dtype_code(dt), None, 64, ptr(x), stream())
+    with pytest.raises(ValueError):        # tokens that are not whole samples
+        call("unetk_layernorm_bwd_partials", ptr(x), ptr(x), ptr(gamma), ptr(stat), ptr(stat), None, ptr(x), ptr(part),
+             64, 96, dtype_code(dt), ptr(stat), 48, ptr(x), stream())
+    with pytest.raises(ValueError):
+        call("unetk_partial_sums_batched", None, 1, 96, stream())
+    with pytest.raises(ValueError):
+        call("unetk_dtable_reduce_batched", ptr(stat), 0, 3, stream())
+    w2 = torch.zeros(4 * 24, 64, device="cuda")
+    pk = ops.PackedConv(w2, dt, transpose=True)
+    dout = torch.zeros(1, 16, 16, 24, device="cuda", dtype=dt)
+    assert ops.convT2x2_bwd_data(dout, 24, pk, 8, 8) is None          # up = 24: the caller takes the un-shuffle route
+    with pytest.raises(ValueError):
+        call("unetk_convt2x2_bwd_data", ptr(dout), 24, ptr(pk.data), ptr(x), 64, 1, 8, 8, 24, 64, pk.bn, dtype_code(dt),
+             stream())
+    with pytest.raises(ValueError):
+        ops.pack_many([(torch.zeros(8, 4, 3, 3, device="cuda"), "convt")], dt)
