@@ -508,6 +508,145 @@ def gen_swin2(swin):
     print("swin2.npz", len(out), "entries")
 
 
+MASKED_UNET = [("small", 1234), ("ragged", 77), ("f48", 5)]      # case of UNET_CASES, torch seed of the draw
+MASKED_SWIN = [("s64", 2, 64, 64, 16), ("s256", 1, 256, 256, 17), ("s24", 2, 24, 24, 3)]
+
+
+def gen_masked(tr, swin):
+    """Train-mode forward + BACKWARD with live Dropout2d (training.py:530) / DropPath (swin_unet_model.py:139-158,
+    371-372).  The keep factors are the ones a seeded fp32 run of the reference draws (checked: the seeded fp32
+    reference run and the same modules with those factors patched in give identical bits); the frozen numbers come
+    from the reference in float64 with the factors patched into its Dropout2d / DropPath modules, for the reason
+    given in gen_swin (fp32 gradients of either implementation carry rounding noise of their own)."""
+    out = {}
+    for name, seed in MASKED_UNET:
+        _, cin, f, B, H, Wd = next(c for c in UNET_CASES if c[0] == name)
+        sd = W.fill_state_dict(W.unet_template(cin, 1, f), seed=42)
+        x, y, w = W.synthetic_batch(B, cin, H, Wd, seed=42)
+        torch.manual_seed(seed)
+        masks = unet_oracle.draw_dropout_masks(B, f)
+        assert any(bool((m == 0).any()) for m in masks), f"{name}: seed {seed} drops nothing"
+
+        def patched(dtype):
+            ref = tr.OptimizedUNet(cin, 1, f).to(dtype)
+            ref.load_state_dict({k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()})
+            ref.train()
+            for blk, m in zip(unet_oracle.BLOCKS, masks):
+                drop = getattr(ref, blk)[6]
+                assert isinstance(drop, torch.nn.Dropout2d)
+                drop.forward = (lambda t, k=m.to(dtype): t * k.view(k.shape[0], k.shape[1], 1, 1))
+            return ref
+        seeded = tr.OptimizedUNet(cin, 1, f)
+        seeded.load_state_dict(sd)
+        seeded.train()
+        torch.manual_seed(seed)
+        assert torch.equal(seeded(x), patched(torch.float32)(x)), f"{name}: patched masks are not the seeded draw"
+        ref64 = patched(torch.float64)
+        x64, y64 = x.double(), y.double()
+        xr_ = x64.clone().requires_grad_(True)
+        r_out = ref64(xr_)
+        r_loss = ((r_out - y64) ** 2).mean()
+        r_loss.backward()
+        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+        o_out, o_loss, o_g, o_stats = unet_oracle.unet_fwd_bwd(sd64, x64, lambda o: ((o - y64) ** 2).mean(),
+                                                                [m.double() for m in masks])
+        close(o_out, r_out, 1e-12, f"masked unet {name} out")
+        rsd = ref64.state_dict()
+        for k, p in ref64.named_parameters():
+            close(o_g[k], p.grad, 1e-9, f"masked unet {name} grad {k}")
+        close(o_g["__input__"], xr_.grad, 1e-9, f"masked unet {name} grad input")
+        for k, v in o_stats.items():
+            close(v, rsd[k], 1e-12, f"masked unet {name} stat {k}")
+        pre = f"unet.{name}"
+        out[f"{pre}.seed"] = np.int64(seed)
+        out[f"{pre}.dropped"] = np.array([int((m == 0).sum()) for m in masks])
+        out[f"{pre}.train_out"] = sub(r_out, 16384)
+        out[f"{pre}.loss"] = np.float64(r_loss.item())
+        out[f"{pre}.param_names"] = np.array([k for k, _ in ref64.named_parameters()])
+        out[f"{pre}.grad_norms"] = np.array([p.grad.norm().item() for _, p in ref64.named_parameters()])
+        out[f"{pre}.grad_heads"] = np.concatenate([sub(p.grad, 16) for _, p in ref64.named_parameters()])
+        out[f"{pre}.grad_input"] = sub(xr_.grad, 4096)
+        stat_names = sorted(o_stats)
+        out[f"{pre}.stat_names"] = np.array(stat_names)
+        out[f"{pre}.stats"] = np.concatenate([sub(rsd[k], 8) for k in stat_names])
+        print(pre, "dropped channels per block", out[f"{pre}.dropped"].tolist())
+    cfg = dict(swin_oracle.DEFAULT_CONFIG)
+    ref32 = swin.SwinUNet(dict(cfg, use_checkpoint=False))
+    sd = W.fill_state_dict({k: v for k, v in ref32.state_dict().items()}, seed=42)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    for name, B, H, Wd, seed in MASKED_SWIN:
+        x, y, w = W.synthetic_batch(B, 4, H, Wd, seed=42)
+        torch.manual_seed(seed)
+        dp = swin_oracle.draw_drop_path(cfg, B)
+        assert any(k is not None and bool((k == 0).any()) for pair in dp for k in pair), f"{name}: nothing dropped"
+
+        def patch(model, dtype):
+            blocks = [blk for layer in model.layers for blk in layer.blocks]
+            assert len(blocks) == len(dp)
+            for blk, pair in zip(blocks, dp):
+                if pair[0] is None:
+                    assert not isinstance(blk.drop_path, swin.DropPath)
+                    continue
+                assert isinstance(blk.drop_path, swin.DropPath)
+                state = {"n": 0}
+
+                def fwd(t, pair=pair, state=state):       # called for the attention branch, then for the MLP branch
+                    k = pair[state["n"] % 2].to(dtype)
+                    state["n"] += 1
+                    return t * k.view(-1, 1, 1)
+                blk.drop_path.forward = fwd
+            return model
+        ref32.load_state_dict(sd)
+        ref32.train()
+        torch.manual_seed(seed)
+        r_seeded = ref32(x)
+        p32 = swin.SwinUNet(dict(cfg, use_checkpoint=False))
+        p32.load_state_dict(sd)
+        p32.train()
+        # x.div(keep) * floor(...) against x * (floor(...)/keep): the same number to an ulp per branch
+        close(patch(p32, torch.float32)(x), r_seeded, 1e-5, f"masked swin {name}: patched factors vs the seeded draw")
+        ref64 = swin.SwinUNet(dict(cfg, use_checkpoint=False)).double()
+        ref64.load_state_dict(sd64)
+        ref64.train()
+        patch(ref64, torch.float64)
+        x64 = x.double()
+        xr_ = x64.clone().requires_grad_(True)
+        r_out = ref64(xr_)
+        tgt = torch.nn.functional.interpolate(y.double(), size=r_out.shape[-2:], mode="bilinear", align_corners=False)
+        r_loss = ((r_out - tgt) ** 2).mean()
+        r_loss.backward()
+        params = {k: v.clone().requires_grad_(True) for k, v in sd64.items()
+                  if v.is_floating_point() and "running_" not in k}
+        full = dict(sd64)
+        full.update(params)
+        xo = x64.clone().requires_grad_(True)
+        dp64 = [[None if k is None else k.double() for k in pair] for pair in dp]
+        o_out, o_stats = swin_oracle.swin_unet_forward(full, xo, cfg, True, dp64)
+        ((o_out - tgt) ** 2).mean().backward()
+        close(o_out, r_out, 1e-12, f"masked swin {name} out")
+        rsd = ref64.state_dict()
+        for k, p in ref64.named_parameters():
+            if k == "final_conv.0.bias":
+                continue
+            close(params[k].grad, p.grad, 1e-9, f"masked swin {name} grad {k}")
+        close(xo.grad, xr_.grad, 1e-9, f"masked swin {name} grad input")
+        pre = f"swin.{name}"
+        out[f"{pre}.seed"] = np.int64(seed)
+        out[f"{pre}.dropped"] = np.array([0 if k is None else int((k == 0).sum()) for pair in dp for k in pair])
+        out[f"{pre}.train_out"] = sub(r_out, 16384)
+        out[f"{pre}.loss"] = np.float64(r_loss.item())
+        out[f"{pre}.param_names"] = np.array([k for k, _ in ref64.named_parameters()])
+        out[f"{pre}.grad_norms"] = np.array([p.grad.norm().item() for _, p in ref64.named_parameters()])
+        out[f"{pre}.grad_heads"] = np.concatenate([sub(p.grad, 16) for _, p in ref64.named_parameters()])
+        out[f"{pre}.grad_input"] = sub(xr_.grad, 4096)
+        stat_names = sorted(o_stats)
+        out[f"{pre}.stat_names"] = np.array(stat_names)
+        out[f"{pre}.stats"] = np.concatenate([sub(rsd[k], 8) for k in stat_names])
+        print(pre, "dropped samples per branch", out[f"{pre}.dropped"].tolist())
+    np.savez_compressed(os.path.join(HERE, "masked.npz"), **out)
+    print("masked.npz", len(out), "entries")
+
+
 SWIN_STEP_LOSS = dict(comb="weighted_mse_grad", grad_w=0.3, spec_w=0.0)      # SWIN_LOSS_CONFIGS['tid_gradient']
 
 
@@ -655,7 +794,7 @@ def gen_filter():
 if __name__ == "__main__":
     torch.set_num_threads(8)
     tr, etml, swin, lap = import_reference()
-    which = sys.argv[1:] or ["unet", "loss", "tile", "swin", "step", "patch", "filter", "bf16", "swin2", "step_swin"]
+    which = sys.argv[1:] or ["unet", "loss", "tile", "swin", "step", "patch", "filter", "bf16", "swin2", "step_swin", "masked"]
     if "unet" in which:
         gen_unet(tr)
     if "loss" in which:
@@ -672,6 +811,8 @@ if __name__ == "__main__":
         gen_swin2(swin)
     if "step_swin" in which:
         gen_step_swin(swin, etml)
+    if "masked" in which:
+        gen_masked(tr, swin)
     if "patch" in which:
         gen_patch(etml)
     if "filter" in which:

@@ -304,3 +304,52 @@ def test_filter_oracle_matches_golden_and_scipy(golden, case):
     direct = gaussian_filter(np.nan_to_num(x, nan=0.0), sigma=[s_lat, s_lon], mode="reflect")
     m = ~np.isnan(x)
     assert np.max(np.abs(direct[m] - got[m])) <= 1e-13 * scale
+
+
+@pytest.mark.parametrize("name,seed", [("small", 1234), ("ragged", 77), ("f48", 5)])
+def test_unet_oracle_backward_with_seeded_dropout_matches_golden(golden, name, seed):
+    """masked.npz: the reference in float64, train mode, with the Dropout2d factors of a seeded run."""
+    g = golden("masked")
+    pre = f"unet.{name}"
+    cin, f, B, H, Wd = UNET_CASES[name]
+    sd = W.fill_state_dict(W.unet_template(cin, 1, f), seed=42)
+    sd = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    x, y, _ = W.synthetic_batch(B, cin, H, Wd, seed=42)
+    torch.manual_seed(seed)
+    masks = [m.double() for m in unet_oracle.draw_dropout_masks(B, f)]
+    assert [int((m == 0).sum()) for m in masks] == g[f"{pre}.dropped"].tolist()
+    out, loss, grads, stats = unet_oracle.unet_fwd_bwd(sd, x.double(), lambda o: ((o - y.double()) ** 2).mean(), masks)
+    assert rel(sub(out, 16384), g[f"{pre}.train_out"]) < 1e-12
+    assert abs(loss.item() - g[f"{pre}.loss"]) < 1e-12
+    names = [str(s) for s in g[f"{pre}.param_names"]]
+    assert rel(np.array([grads[k].norm().item() for k in names]), g[f"{pre}.grad_norms"]) < 1e-9
+    assert rel(np.concatenate([sub(grads[k], 16) for k in names]), g[f"{pre}.grad_heads"]) < 1e-9
+    assert rel(sub(grads["__input__"], 4096), g[f"{pre}.grad_input"]) < 1e-9
+
+
+@pytest.mark.parametrize("name,B,H,Wd,seed", [("s64", 2, 64, 64, 16), ("s24", 2, 24, 24, 3)])
+def test_swin_oracle_backward_with_seeded_droppath_matches_golden(golden, name, B, H, Wd, seed):
+    g = golden("masked")
+    pre = f"swin.{name}"
+    cfg = dict(swin_oracle.DEFAULT_CONFIG)
+    sd = W.fill_state_dict(swin_oracle.swin_template(cfg), seed=42)
+    sd = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    x, y, _ = W.synthetic_batch(B, 4, H, Wd, seed=42)
+    torch.manual_seed(seed)
+    dp = [[None if k is None else k.double() for k in pair] for pair in swin_oracle.draw_drop_path(cfg, B)]
+    assert [0 if k is None else int((k == 0).sum()) for pair in dp for k in pair] == g[f"{pre}.dropped"].tolist()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running_" not in k}
+    full = dict(sd)
+    full.update(params)
+    xo = x.double().requires_grad_(True)
+    out, _ = swin_oracle.swin_unet_forward(full, xo, cfg, True, dp)
+    tgt = torch.nn.functional.interpolate(y.double(), size=out.shape[-2:], mode="bilinear", align_corners=False)
+    loss = ((out - tgt) ** 2).mean()
+    loss.backward()
+    assert rel(sub(out, 16384), g[f"{pre}.train_out"]) < 1e-12
+    assert abs(loss.item() - g[f"{pre}.loss"]) < 1e-12
+    names = [str(s) for s in g[f"{pre}.param_names"]]
+    keep = np.array([k != "final_conv.0.bias" for k in names])
+    norms = np.array([params[k].grad.norm().item() for k in names])
+    assert rel(norms[keep], g[f"{pre}.grad_norms"][keep]) < 1e-9
+    assert rel(sub(xo.grad, 4096), g[f"{pre}.grad_input"]) < 1e-9
