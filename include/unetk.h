@@ -219,7 +219,9 @@ int unetk_loss_pixgrad_fwd(const float* pred, const float* target, const float* 
  * This entry point has no counterpart in the reference.  It allocates nothing and gives the same
  * bits as unetk_loss_pixgrad_fwd.  B*H*W may be at most unetk_loss_static_max_pixels() (2^30);
  * larger inputs are refused with UNETK_EINVAL.  All calls on one GPU share that GPU's array:
- * calls that overlap on one GPU (different streams) race; calls on one stream are ordered. */
+ * calls that overlap on one GPU (different streams) race; calls on one stream are ordered.
+ * The GPU that owns the inputs and the stream must be the CURRENT device: a stream that belongs to
+ * another device is refused with UNETK_EINVAL (its kernels would be handed this device's array). */
 int64_t unetk_loss_static_max_pixels(void);
 int unetk_loss_pixgrad_fwd_static(const float* pred, const float* target, const float* w, int B, int H, int W,
                                   int pixel_mae, int grad_method, int pixel_use_w, float tid_scale, float* gx,

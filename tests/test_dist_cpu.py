@@ -223,6 +223,109 @@ def test_dp_step_equals_mean_of_per_shard_reference_gradients(world):
     assert any(not torch.allclose(a, b, rtol=1e-3, atol=1e-6) for a, b in zip(big, want))
 
 
+class _SinkNet(torch.nn.Module):
+    """A model of the unet_amd kind on the CPU: its whole backward is ONE autograd node that hands every parameter
+    gradient to ``grad_sink(name, grad)`` the moment it exists (here: two linear layers and a ReLU by hand)."""
+
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Linear(23, 31)
+        self.b = torch.nn.Linear(31, 5)
+        self.grad_sink = None
+
+    def forward(self, x):
+        return _SinkFn.apply(x, self, *[p for _, p in self.named_parameters()])
+
+
+class _SinkFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, model, *params):
+        with torch.no_grad():
+            h = torch.relu(model.a(x))
+            out = model.b(h)
+        ctx.model, ctx.saved = model, (x, h)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from unet_amd.ops import GradOut
+        m = ctx.model
+        x, h = ctx.saved
+        grads = GradOut(m.grad_sink)
+        grads["b.weight"], grads["b.bias"] = dout.t() @ h, dout.sum(0)          # last layer first, as a backward runs
+        dh = (dout @ m.b.weight) * (h > 0)
+        grads["a.weight"], grads["a.bias"] = dh.t() @ x, dh.sum(0)
+        return (None, None) + tuple(grads[n] for n, _ in m.named_parameters())
+
+
+def _sink_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from unet_amd.dist import GradReducer, broadcast_parameters
+    torch.manual_seed(77 + rank)
+    m = _SinkNet()
+    broadcast_parameters(m)
+    red = GradReducer(m, bucket_bytes=512)           # default collective: asynchronous dist.all_reduce work handles
+    assert m.grad_sink is not None and len(red.buckets) >= 3
+    g = torch.Generator().manual_seed(900 + rank)
+    xs = [torch.randn(6, 23, generator=g) for _ in range(3)]
+    res, launched = [], []
+    for step, x in enumerate(xs):
+        # step 0: set_to_none=True; step 1: set_to_none=False (the .grad tensors are last step's bucket views);
+        # step 2: no zero_grad at all - a .grad that aliases its bucket view is replaced, never added to itself
+        if step == 0:
+            m.zero_grad(set_to_none=True)
+        elif step == 1:
+            m.zero_grad(set_to_none=False)
+        m(x).square().sum().backward()
+        launched.append(sum(b.work is not None for b in red.buckets))
+        red.finish()
+        res.append([p.grad.numpy().copy() for p in m.parameters()])
+    # a second backward before finish() is refused (gradient accumulation is not supported by the reducer)
+    m.zero_grad(set_to_none=True)
+    m(xs[0]).sum().backward()
+    try:
+        m(xs[0]).sum().backward()
+        second = "no error"
+    except RuntimeError as e:
+        second = str(e)
+    red.finish()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (res, launched, second))
+    if rank == 0:
+        q.put(gathered)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_sink_path_with_default_collective():
+    """The sink path (one autograd node per model, gradients handed over inside the backward) with the DEFAULT
+    collective - asynchronous ``dist.all_reduce`` work handles launched from the autograd thread, ``finish()``
+    waits - over several buckets and three steps with the three zero_grad habits."""
+    world = 2
+    gathered = _spawn(_sink_worker, world, 35500 + os.getpid() % 2000)
+    torch.manual_seed(77)
+    init = _SinkNet().state_dict()
+    want = []
+    for step in range(3):
+        per = []
+        for r in range(world):
+            m = _SinkNet()
+            m.load_state_dict(init)
+            g = torch.Generator().manual_seed(900 + r)
+            xs = [torch.randn(6, 23, generator=g) for _ in range(3)]
+            ref = torch.nn.Sequential(m.a, torch.nn.ReLU(), m.b)
+            ref(xs[step]).square().sum().backward()
+            per.append([p.grad.clone() for p in m.parameters()])
+        want.append([sum(gs) / world for gs in zip(*per)])
+    for r, (res, launched, second) in enumerate(gathered):
+        for step in range(3):
+            for a, b in zip(res[step], want[step]):
+                assert torch.allclose(torch.from_numpy(a), b, rtol=1e-5, atol=1e-6), (r, step)
+        assert all(n >= 2 for n in launched), launched       # every full bucket went out inside the backward
+        assert "second gradient" in second, second
+
+
 def test_bench_launcher_starts_ranks_and_prints_one_line():
     """`python bench.py --gpus 2` with WORLD_SIZE unset starts two rank processes itself (rehearsed on the CPU:
     gloo rendezvous, one reduction) and rank 0 prints the one JSON line with n_gpus 2."""

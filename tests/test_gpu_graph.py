@@ -89,3 +89,66 @@ def test_graphed_step_rejects_host_side_optimizer():
     x = torch.zeros(1, 4, 32, 32, device=dev)
     with pytest.raises(ValueError):
         GraphedTrainStep(m, MultiLossFunction(loss_oracle.preset("all")), opt, x, torch.zeros(1, 1, 32, 32, device=dev))
+
+
+def test_graphed_step_resumes_from_a_checkpoint_and_survives_an_eager_step():
+    """An optimizer loaded from a checkpoint with step > 0 keeps that step through the construction of the graph
+    (the warm-up steps are undone back to the loaded counter, not to zero), graph replays and an eager step in
+    between (a short last batch) follow the eager optimizer, and state_dict() reports the true step count."""
+    from oracle import loss_oracle
+    from unet_amd.graph import GraphedTrainStep
+    from unet_amd.losses import MultiLossFunction
+    from unet_amd.optim import FusedAdamW
+    dev = torch.device("cuda:0")
+    mk, shape, oshape, post = _models("unet")
+    crit = MultiLossFunction(loss_oracle.preset("weighted_mse_grad", grad_w=0.3, spec_w=0.0)).to(dev)
+    g = torch.Generator().manual_seed(9)
+    batches = [(torch.randn(shape, generator=g).to(dev), torch.randn(oshape, generator=g).to(dev),
+                torch.rand(oshape, generator=g).to(dev)) for _ in range(7)]
+    short = (torch.randn((2,) + shape[1:], generator=g).to(dev), torch.randn((2,) + oshape[1:], generator=g).to(dev),
+             torch.rand((2,) + oshape[1:], generator=g).to(dev))
+
+    def eager(m, opt, x, y, w):
+        opt.zero_grad(set_to_none=True)
+        loss, _ = crit(m(x), y, w)
+        loss.backward()
+        opt.step()
+
+    # three eager steps, then a checkpoint of model + optimizer (what the reference trainer saves)
+    first = mk().to(dev).train()
+    opt0 = FusedAdamW(first.parameters(), lr=2e-3, weight_decay=0.05, max_grad_norm=1.0)
+    for b in batches[:3]:
+        eager(first, opt0, *b)
+    ck_model = {k: v.clone() for k, v in first.state_dict().items()}
+    import copy
+    ck_opt = copy.deepcopy(opt0.state_dict())
+    assert all(float(s["step"]) == 3 for s in ck_opt["state"].values())
+    ref, got = mk().to(dev).train(), mk().to(dev).train()
+    ref.load_state_dict(ck_model)
+    got.load_state_dict(ck_model)
+    opt_ref = FusedAdamW(ref.parameters(), lr=2e-3, weight_decay=0.05, max_grad_norm=1.0)
+    opt_got = FusedAdamW(got.parameters(), lr=2e-3, weight_decay=0.05, max_grad_norm=1.0, capturable=True)
+    opt_ref.load_state_dict(copy.deepcopy(ck_opt))      # (load_state_dict adopts tensors that need no cast)
+    opt_got.load_state_dict(copy.deepcopy(ck_opt))
+    step = GraphedTrainStep(got, crit, opt_got, *batches[3], post=post, warmup=2)
+    assert opt_got.device_step_count() == 3
+    for i, b in enumerate(batches[3:]):
+        eager(ref, opt_ref, *b)
+        step(*b)
+        if i == 1:          # a batch of another shape cannot use the captured graph: eager step in between
+            eager(ref, opt_ref, *short)
+            eager(got, opt_got, *short)
+    nsteps = 3 + len(batches[3:]) + 1
+    assert opt_got.device_step_count() == nsteps
+    sd_got, sd_ref = opt_got.state_dict(), opt_ref.state_dict()
+    assert all(float(s["step"]) == nsteps for s in sd_got["state"].values())
+    assert all(float(s["step"]) == nsteps for s in sd_ref["state"].values())
+    for (n, a), b in zip(ref.named_parameters(), got.parameters()):
+        np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().cpu().numpy(), rtol=1e-4, atol=2e-6, err_msg=n)
+    for k, s in sd_ref["state"].items():
+        np.testing.assert_allclose(sd_got["state"][k]["exp_avg"].cpu().numpy(), s["exp_avg"].cpu().numpy(),
+                                   rtol=1e-3, atol=1e-7)
+    # and the checkpoint written in capturable mode resumes an ordinary optimizer at the right step
+    opt_new = FusedAdamW(ref.parameters(), lr=2e-3, weight_decay=0.05, max_grad_norm=1.0)
+    opt_new.load_state_dict(copy.deepcopy(sd_got))
+    assert all(int(opt_new.state[p]["step"]) == nsteps for p in ref.parameters())

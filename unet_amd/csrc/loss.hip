@@ -365,13 +365,28 @@ std::mutex g_scratch_mu;
 float* g_scratch_ptr[MAX_DEVICES];      // device address of `scratch` on each GPU, looked up once
 
 // The array's name is only a host-side handle: kernels must be given its device address.
-int scratch_address(float** out) {
+// The address belongs to the CURRENT device; a stream of another GPU would hand that GPU's kernels this GPU's
+// copy of the array (a peer access, or a fault without peer access), so such a call is refused.
+int scratch_address(float** out, hipStream_t stream) {
   int dev = -1;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess || dev < 0 || dev >= MAX_DEVICES) {
     unetk_set_error("loss_pixgrad_fwd_static: hipGetDevice failed or device index %d outside [0,%d)", dev,
                     MAX_DEVICES);
     return UNETK_EHIP;
+  }
+  if (stream != nullptr) {
+    int sdev = -1;
+    e = hipStreamGetDevice(stream, &sdev);
+    if (e != hipSuccess) {
+      unetk_set_error("loss_pixgrad_fwd_static: hipStreamGetDevice failed: %s", hipGetErrorString(e));
+      return UNETK_EHIP;
+    }
+    if (sdev != dev) {
+      unetk_set_error("loss_pixgrad_fwd_static: the stream belongs to device %d but device %d is current; make the "
+                      "stream's device current before the call", sdev, dev);
+      return UNETK_EINVAL;
+    }
   }
   std::lock_guard<std::mutex> lock(g_scratch_mu);
   if (g_scratch_ptr[dev] == nullptr) {
@@ -432,7 +447,7 @@ int unetk_loss_pixgrad_fwd_static(const float* pred, const float* target, const 
   UNETK_CHECK_ARG(nblk <= MAX_LOSS_BLOCKS, "loss_pixgrad_fwd_static: %d partial sums exceed the library's %d", nblk,
                   MAX_LOSS_BLOCKS);
   float* partials = nullptr;
-  const int rc = scratch_address(&partials);
+  const int rc = scratch_address(&partials, stream);
   if (rc != UNETK_OK) return rc;
   LossCfg c = make_cfg(B, H, W, pixel_mae, grad_method, pixel_use_w && w != nullptr, w != nullptr, tid_scale,
                        0.f, 0.f, 0.f, 0.f);

@@ -17,6 +17,10 @@ Two ways a gradient reaches its bucket:
    installs itself as that sink.
  * any other ``nn.Module``: a post-accumulate-grad hook per parameter.
 After ``finish()`` every ``.grad`` is a view into its bucket (averaged over the ranks).
+
+One backward pass per ``finish()``: gradient accumulation over several backward passes is not supported (the
+second pass raises).  ``zero_grad(set_to_none=False)`` is fine: a ``.grad`` that still aliases its bucket view is
+dropped before the new gradient is handed to autograd, which would otherwise add the view to itself.
 """
 from typing import Dict, List, Optional
 
@@ -106,9 +110,17 @@ class GradReducer:
         if not self._armed:
             self._arm()
         b = self.bucket_of[name]
+        if b.pending <= 0:
+            raise RuntimeError(f"GradReducer: a second gradient for '{name}' arrived before finish(); one backward "
+                               "pass per finish() (gradient accumulation is not supported)")
         view = b.views[name]
         view.copy_(grad.reshape(view.shape))
         self._arrived(b)
+        p = self.params[name]
+        if p.grad is not None and p.grad.data_ptr() == view.data_ptr():
+            # left over from the last step (zero_grad(set_to_none=False) or none at all): autograd would do
+            # ``p.grad += view`` on the same memory, doubling the bucket after its all-reduce was launched
+            p.grad = None
         return view.detach()        # a fresh alias of the bucket memory, for autograd to keep as .grad
 
     def _make_hook(self, name):

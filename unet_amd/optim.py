@@ -10,7 +10,8 @@ Both walk the whole parameter list in one kernel launch each (device arrays of p
 chunk table), instead of one small launch per tensor.  ``FusedAdamW(max_grad_norm=1.0)`` fuses
 the two: the norm kernel leaves the clip coefficient on the device and the update applies it
 while it reads the gradients.  State keys (``step``, ``exp_avg``, ``exp_avg_sq``) are torch's, so
-optimizer checkpoints interchange.  GPU tensors only.
+optimizer checkpoints interchange (``state_dict()`` writes the device-resident step count of the capturable
+mode into every ``step`` entry; ``load_state_dict()`` seeds the device counter from the loaded one).  GPU tensors only.
 """
 from typing import Iterable, List, Optional
 
@@ -48,14 +49,24 @@ class _TensorList:
         """Device array of the tensors' addresses.  The last table of each slot is kept (parameters
         and moments never move; re-allocated gradients usually come back at the same addresses);
         a changed table goes up from pinned memory without blocking the host, so the launch queue
-        never drains."""
+        never drains.
+
+        A table uploaded while a HIP graph is being captured (gradients re-allocated in the graph's pool)
+        becomes a copy node that reads the pinned host block again on every replay: such tables are kept for
+        the life of the process (``_CAPTURED``), so that a later eager step, which replaces the slot, cannot hand
+        the block back to the allocator under a graph that still reads it."""
         key = tuple(t.data_ptr() for t in tensors)
         hit = self._tables.get(slot)
         if hit is None or hit[0] != key:
             host = torch.tensor(key, dtype=torch.int64).pin_memory()
             hit = (key, host.to(self.device, non_blocking=True), host)
             self._tables[slot] = hit
+            if torch.cuda.is_current_stream_capturing():
+                _CAPTURED.append(hit)
         return hit[1]
+
+
+_CAPTURED: list = []        # (key, device table, pinned host block) of every upload recorded into a HIP graph
 
 
 def _grads_of(params: List[torch.Tensor]) -> List[torch.Tensor]:
@@ -129,8 +140,47 @@ class FusedAdamW(torch.optim.Optimizer):
                 hit[0][1:].copy_(torch.tensor(now, dtype=torch.float64), non_blocking=False)
                 hit[2] = now
 
+    # ------------------------------------------------------------------ checkpoints
+    def _pull_device_steps(self):
+        """Capturable mode: graph replays advance only the device counter; bring the host-side ``step`` entries
+        (what torch's state_dict() saves) up to it."""
+        for gi, group in enumerate(self.param_groups):
+            hit = self._hyper.get(gi)
+            if hit is None:
+                continue
+            n = float(hit[0][0].item())
+            for p in group["params"]:
+                st = self.state.get(p)
+                if st:
+                    st["step"].fill_(n)
+
+    def state_dict(self):
+        self._pull_device_steps()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for gi, group in enumerate(self.param_groups):
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                st = self.state.get(p)
+                if st and torch.is_tensor(st.get("step")) and st["step"].is_cuda:
+                    st["step"] = st["step"].detach().cpu().to(torch.float32)      # host-side counter, as step() makes it
+            hit = self._hyper.get(gi)
+            if hit is not None:         # the same device tensors a captured graph reads: updated in place
+                step0 = next((float(self.state[p]["step"]) for p in group["params"] if self.state.get(p)), 0.0)
+                now = (group["lr"], group["weight_decay"], b1, b2)
+                hit[0].copy_(torch.tensor((step0,) + now, dtype=torch.float64))
+                hit[2] = now
+
     def snapshot(self):
-        """Copies of the moments and step counts, for ``restore`` (a graph capture's warm-up steps are undone)."""
+        """Copies of the moments and step counts, for ``restore`` (a graph capture's warm-up steps are undone).
+        In capturable mode the device-resident counters are created here, from the state's step counts (zero, or
+        what a checkpoint brought), so that they are part of the snapshot."""
+        if self.capturable:
+            for gi, group in enumerate(self.param_groups):
+                if group["params"]:
+                    self._hyper_for(gi, group, group["params"][0].device)
         snap = {}
         for group in self.param_groups:
             for p in group["params"]:
@@ -158,8 +208,9 @@ class FusedAdamW(torch.optim.Optimizer):
         for gi, h in self._hyper.items():
             if gi in steps:
                 h[0][0:1].copy_(steps[gi])
-            else:
-                h[0][0:1].zero_()
+            else:       # a counter made after the snapshot: back to the snapshot's step count
+                old = next((states[p] for p in self.param_groups[gi]["params"] if p in states), None)
+                h[0][0:1].fill_(float(old["step"]) if old is not None else 0.0)
 
     def device_step_count(self, gi=0):
         hit = self._hyper.get(gi)
