@@ -67,6 +67,7 @@ def parse(argv=None):
     ap.add_argument("--no-small-batch", action="store_true", help="swin: skip the batch-6 graph/eager comparison")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="predict: skip the host-to-host timing of predict_large_area")
     return ap.parse_args(argv)
 
 
@@ -480,51 +481,128 @@ def run_swin(args, rank, world, dev, dt):
     return rec
 
 
+RIDGE_FLOP_PER_BYTE = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)      # 312.5
+
+
+def pmc_entry(table, kernel):
+    """A row of a frozen rocprofv3 --pmc table (profiles/<table>.json, written by tools/pmc_traffic.py from separate
+    counter passes of the same bench command), or {}."""
+    try:
+        with open(os.path.join(ROOT, "profiles", table + ".json")) as f:
+            return json.load(f).get(kernel, {})
+    except (OSError, ValueError):
+        return {}
+
+
 class LinearTimer:
-    """Events around the token-linear launches of the Swin encoder (forward and data gradient): the
-    dominant kernel family of the Swin step.  Priced against HBM: at 96..768 channels a token linear
-    moves (Ci + Co) x 2 bytes per token against 2 x Ci x Co FLOP, below the 312 FLOP/byte ridge on the
-    stage-0/1 layers that hold most of the tokens."""
+    """Events around every token-GEMM launch of the Swin step (the encoder's nn.Linear layers forward and data
+    gradient, the decoder's ConvTranspose GEMMs forward and data gradient) and around the window-attention
+    launches.  A token linear moves (Ci + Co) x 2 bytes per token against 2 x Ci x Co FLOP: stages 0/1 (96 / 192
+    channels, most of the tokens) sit far below the 312 FLOP/byte ridge and are priced against HBM; stages 2/3
+    and the ConvTranspose GEMMs (384+ channels) sit at or above it and are priced against the MFMA peak."""
 
     def __init__(self):
-        from unet_amd import swin
-        self.swin = swin
-        self.records = []
+        from unet_amd import ops, swin
+        self.swin, self.ops = swin, ops
+        self.records = []          # (e0, e1, flops, bytes)
+        self.attn = []             # (e0, e1, flops, bytes, "fwd" | "bwd")
         self.orig = None
 
     def __enter__(self):
-        self.orig = self.swin._linear_launch
-        orig, records = self.orig, self.records
+        ops = self.ops
+        self.orig = (self.swin._linear_launch, ops.convT2x2_fwd, ops.convT2x2_bwd_data, ops.window_attn_fwd,
+                     ops.window_attn_bwd)
+        o_lin, o_ct, o_ctb, o_af, o_ab = self.orig
+        records, attn = self.records, self.attn
 
-        def timed_linear(x, *a, **k):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = orig(x, *a, **k)
-            e1.record()
+        def bracket(fn, price):
+            def wrapped(*a, **k):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = fn(*a, **k)
+                e1.record()
+                price(e0, e1, r, *a, **k)
+                return r
+            return wrapped
+
+        def lin(e0, e1, r, x, *a, **k):
             out = r[0] if isinstance(r, tuple) else r
-            ntok = x.numel() // x.shape[-1]
-            ci, co = x.shape[-1], out.shape[-1]
+            ntok, ci, co = x.numel() // x.shape[-1], x.shape[-1], out.shape[-1]
             records.append((e0, e1, 2.0 * ntok * ci * co, float((ntok * (ci + co) + ci * co) * x.element_size())))
-            return r
 
-        self.swin._linear_launch = timed_linear
+        def ct_fwd(e0, e1, r, x, pk, bias, cat, *a, **k):       # K -> 4*up GEMM, pixel-shuffled stores
+            ntok, ci, co = x.numel() // x.shape[-1], x.shape[-1], pk.Co
+            records.append((e0, e1, 2.0 * ntok * ci * co, float((ntok * (ci + co) + ci * co) * x.element_size())))
+
+        def ct_bwd(e0, e1, r, dcat, up, pkT, h, w, *a, **k):    # 4*up -> Cin GEMM, gathered operand rows
+            if r is None:
+                return
+            ntok, ci, co = r.numel() // r.shape[-1], 4 * up, r.shape[-1]
+            records.append((e0, e1, 2.0 * ntok * ci * co, float((ntok * (ci + co) + ci * co) * r.element_size())))
+
+        def at_fwd(e0, e1, r, qkv, table, heads, *a, **k):      # per token: read q, k, v, write the output
+            ntok, C = qkv.numel() // qkv.shape[-1], qkv.shape[-1] // 3
+            attn.append((e0, e1, 4.0 * 64 * 32 * ntok * heads, float(ntok * 4 * C * qkv.element_size()), "fwd"))
+
+        def at_bwd(e0, e1, r, qkv, dout, table, heads, *a, **k):   # read qkv and d out, write d qkv; five products
+            ntok, C = qkv.numel() // qkv.shape[-1], qkv.shape[-1] // 3
+            attn.append((e0, e1, 10.0 * 64 * 32 * ntok * heads, float(ntok * 7 * C * qkv.element_size()), "bwd"))
+
+        self.swin._linear_launch = bracket(o_lin, lin)
+        ops.convT2x2_fwd, ops.convT2x2_bwd_data = bracket(o_ct, ct_fwd), bracket(o_ctb, ct_bwd)
+        ops.window_attn_fwd, ops.window_attn_bwd = bracket(o_af, at_fwd), bracket(o_ab, at_bwd)
         return self
 
     def __exit__(self, *exc):
-        self.swin._linear_launch = self.orig
+        ops = self.ops
+        (self.swin._linear_launch, ops.convT2x2_fwd, ops.convT2x2_bwd_data, ops.window_attn_fwd,
+         ops.window_attn_bwd) = self.orig
+
+    @staticmethod
+    def _sum(rows):
+        ms = sum(r[0].elapsed_time(r[1]) for r in rows)
+        return len(rows), ms, sum(r[2] for r in rows), sum(r[3] for r in rows)
 
     def roofline(self, steps):
         if not self.records:
             return None
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in self.records)
-        flops = sum(f for _, _, f, _ in self.records)
-        byts = sum(b for _, _, _, b in self.records)
+        low = [r for r in self.records if r[2] / r[3] < 0.8 * RIDGE_FLOP_PER_BYTE]
+        high = [r for r in self.records if r[2] / r[3] >= 0.8 * RIDGE_FLOP_PER_BYTE]
+        n, ms, flops, byts = self._sum(low)
         gbs = byts / (ms * 1e-3) / 1e9
-        return {"bound": "hbm", "kernel": "token-linear GEMM launches of the Swin encoder (forward + data gradient)",
-                "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-                "traffic": None, "launches_per_step": len(self.records) // steps,
-                "ms_per_step": round(ms / steps, 3), "algorithmic_mb_per_step": round(byts / steps / 1e6, 1),
-                "mfma_tflops": round(flops / (ms * 1e-3) / 1e12, 1)}
+        pm = pmc_entry("pmc_traffic_swin", "void lin_gemm_kernel<2, 6>")
+        out = {"bound": "hbm", "kernel": "lin_gemm_kernel: token GEMMs of Swin stages 0/1 (below 250 FLOP/byte), forward + "
+                                         "data gradient",
+               "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+               "traffic": pm.get("hbm_bytes_per_launch"), "traffic_note": "PMC bytes per launch averaged over ALL launches "
+               "of the kernel (both groups); algorithmic bytes per launch of this group beside it",
+               "launches_per_step": n // steps, "ms_per_step": round(ms / steps, 3),
+               "algorithmic_mb_per_launch": round(byts / max(n, 1) / 1e6, 1),
+               "mfma_tflops": round(flops / (ms * 1e-3) / 1e12, 1)}
+        if high:
+            n2, ms2, fl2, by2 = self._sum(high)
+            tf = fl2 / (ms2 * 1e-3) / 1e12
+            out["mfma_bound_members"] = {
+                "bound": "mfma", "kernel": "lin_gemm_kernel: token GEMMs of stages 2/3 and the ConvTranspose GEMMs "
+                                           "(at or above 250 FLOP/byte)",
+                "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
+                "launches_per_step": n2 // steps, "ms_per_step": round(ms2 / steps, 3),
+                "hbm_gbs": round(by2 / (ms2 * 1e-3) / 1e9, 1)}
+        if self.attn:
+            rows = {}
+            for d, kern in (("fwd", "attn_fwd_bf16_kernel"), ("bwd", "attn_bwd_bf16_kernel")):
+                sel = [r for r in self.attn if r[4] == d]
+                if not sel:
+                    continue
+                n3, ms3, fl3, by3 = self._sum(sel)
+                g3 = by3 / (ms3 * 1e-3) / 1e9
+                pa = pmc_entry("pmc_traffic_swin", kern)
+                rows[d] = {"kernel": kern, "bound": "hbm", "achieved": round(g3, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                           "frac": round(g3 / PEAK_HBM_GBS, 4), "launches_per_step": n3 // steps,
+                           "ms_per_step": round(ms3 / steps, 3), "mfma_tflops": round(fl3 / (ms3 * 1e-3) / 1e12, 2),
+                           "traffic": pa.get("hbm_bytes_per_launch"), "mfma_util_pmc": pa.get("mfma_util")}
+            out["attention"] = rows
+        return out
 
 
 def cpu_baseline_swin(batch, size):
@@ -536,10 +614,10 @@ def cpu_baseline_swin(batch, size):
     sd = W.fill_state_dict(swin_oracle.swin_template(cfg), seed=42)
     x, y, w = W.synthetic_batch(batch, 4, size, size, seed=42)
     lcfg = loss_oracle.preset("weighted_mse_grad", grad_w=0.3, spec_w=0.0)
-    t = median_time(lambda: step_oracle.swin_training_step(sd, x, y, w, cfg, lcfg), warmup=1, iters=3)
+    t = median_time(lambda: step_oracle.swin_training_step(sd, x, y, w, cfg, lcfg), warmup=2, iters=5)
     return {"value": round(batch / t, 3), "unit": "patches/s", "cores": threads, "kind": "port",
-            "sample": f"torch-CPU fp32 oracle of the trainer step, batch {batch} of 4x{size}x{size}, median of 3 after 1 "
-                      f"warm-up, {threads} threads"}
+            "sample": f"torch-CPU fp32 oracle of the trainer step, batch {batch} of 4x{size}x{size}, median of 5 after 2 "
+                      f"warm-ups, {threads} threads"}
 
 
 # ---------------------------------------------------------------------------- tiled prediction
@@ -577,6 +655,7 @@ def run_predict(args, rank, world, dev, dt):
                 pred.predict_device(model, feats)
 
         el = timed(timed_pass, steps, 0, world, dev)
+        e2e = predict_end_to_end(pred, model, feats, world) if not args.no_e2e else None
     ms = el / steps * 1e3
     mpix = args.grid * args.grid / 1e6
     rec = None
@@ -600,10 +679,41 @@ def run_predict(args, rank, world, dev, dt):
             "config": {"workload": f"LargeAreaPredictor over a {args.grid}x{args.grid} grid, 256-px tiles, stride 128 "
                                    f"({ntile} tiles), UNet(4,1,48) eval, Gaussian blend",
                        "parallelism": f"tile-row bands over {world} GPU(s)"},
-            "roofline": roof, "cpu_baseline": cpu}
+            "roofline": roof, "cpu_baseline": cpu, "e2e": e2e}
     del model, feats, pred
     torch.cuda.empty_cache()
     return rec
+
+
+def predict_end_to_end(pred, model, feats, world):
+    """The reference API end to end (large_area_predictor.py:133-219 with its host-device traffic, :187-216): four
+    pageable host arrays in, one host array out.  Never the headline value: reported beside it."""
+    import numpy as np
+    from unet_amd.predictor import FEATURE_VARS
+
+    class HostGrid(dict):
+        def __init__(self, arrays):
+            super().__init__(arrays)
+            a = arrays[FEATURE_VARS[0]]
+            self.lat, self.lon = np.arange(a.shape[0]), np.arange(a.shape[1])
+    host = feats.cpu().numpy()
+    grid = HostGrid({v: np.ascontiguousarray(host[i]) for i, v in enumerate(FEATURE_VARS)})
+    for v in grid:
+        grid[v] = type("V", (), {"values": grid[v]})()
+    ts = []
+    for _ in range(4):
+        barrier_sync(world)
+        t0 = time.perf_counter()
+        out = pred.predict_large_area(model, grid)
+        ts.append(time.perf_counter() - t0)
+    assert out.shape == host.shape[1:]
+    steady = sorted(ts[1:])[1]
+    n = host.shape[1] * host.shape[2]
+    return {"ms": round(steady * 1e3, 2), "Mpix_per_s": round(n / 1e6 / steady, 2), "ms_first_call": round(ts[0] * 1e3, 2),
+            "includes": "predict_large_area from four pageable host arrays to a host array: band rows staged through "
+                        "pinned memory in blocks of 8 tile rows on a copy stream under the network passes of the "
+                        "block before, result back through pinned memory; first call also pins the staging blocks; "
+                        "median of 3 calls after it"}
 
 
 class TileTimer:

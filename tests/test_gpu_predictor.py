@@ -89,6 +89,31 @@ def test_predict_large_area_vs_oracle(dt, tol):
     assert err < tol, err
 
 
+@pytest.mark.parametrize("block", [1, 3])
+@pytest.mark.parametrize("case", CASES[:2], ids=[c[0] for c in CASES[:2]])
+def test_host_path_blocks_match_device_path_bitwise(golden, case, block):
+    """predict_large_area (host arrays in, host array out: band rows uploaded in blocks of `block` tile rows
+    through pinned memory on a copy stream, overlapped with the network passes) against predict_device on the
+    resident grid and the frozen reference output positions: the same bits whatever the block size."""
+    from unet_amd.predictor import LargeAreaPredictor
+    name, lat, lon, P, S, nb, sp = case
+    feats = toy_features(lat, lon, 11, nb, sp)
+    model, sd = make_model(torch.float32)
+    cfg = cfg_for(P, S)
+    cfg.HOST_BLOCK_TILE_ROWS = block
+    pred = LargeAreaPredictor(cfg)
+    pred.keep_tile_predictions = True
+    out = pred.predict_large_area(model, _DS(feats))
+    pos, _ = pred.last_tile_predictions
+    assert np.array_equal(pos, golden("tile")[name + ".pos"])
+    whole = LargeAreaPredictor(cfg_for(P, S))
+    f = torch.from_numpy(np.stack([feats[v] for v in tile_oracle.FEATURE_VARS])).cuda()
+    want = whole.predict_device(model, f).cpu().numpy()
+    assert np.array_equal(out, want)
+    again = pred.predict_large_area(model, _DS(feats))          # the staging buffers are re-used
+    assert np.array_equal(again, want)
+
+
 def test_missing_variable_and_cpu_model():
     from unet_amd.predictor import LargeAreaPredictor
     feats = toy_features(80, 80, 3)

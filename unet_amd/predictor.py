@@ -120,11 +120,15 @@ def _feature_array(features, var, lat, lon):
 class HipTileBackend:
     """The device side of the tiled predictor: four libunetk kernels and the UNet eval engine."""
 
-    def valid(self, feats, P, S, nti, ntj):
+    def valid_device(self, feats, P, S, nti, ntj):
+        """int32 flags on the device, queued on the current stream (no host synchronisation)."""
         nvar, lat, lon = feats.shape
         v = torch.empty(nti * ntj, dtype=torch.int32, device=feats.device)
         call("unetk_tile_valid", ptr(feats), nvar, lat, lon, P, S, nti, ntj, ptr(v), stream())
-        return v.cpu().numpy().astype(bool)
+        return v
+
+    def valid(self, feats, P, S, nti, ntj):
+        return self.valid_device(feats, P, S, nti, ntj).cpu().numpy().astype(bool)
 
     def make_engine(self, model):
         from .unet import EvalEngine
@@ -215,7 +219,21 @@ class LargeAreaPredictor:
         return path
 
     # ------------------------------------------------------------------ core
+    def _plan(self, lat, lon):
+        import torch.distributed as dist
+        P, S = int(self.config.PATCH_SIZE), int(self.config.STRIDE)
+        nti, ntj = (lat - P) // S + 1, (lon - P) // S + 1
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        rank = dist.get_rank() if world > 1 else 0
+        if world > nti:
+            raise ValueError(f"{world} ranks for {nti} tile rows: use at most one rank per tile row")
+        return P, S, nti, ntj, world, rank, band_partition(nti, world)
+
     def predict_large_area(self, model, features, device: Optional[torch.device] = None) -> np.ndarray:
+        """large_area_predictor.py:133-219 from host arrays to a host array.  Every rank uploads only the grid rows
+        of its own band of tile rows (+ the P - S rows its last tiles reach into), in blocks of a few tile rows
+        staged through pinned memory on a copy stream, so that the upload of block k+1 runs under the network
+        passes of block k; the blended map comes back through pinned memory."""
         P = int(self.config.PATCH_SIZE)
         lat, lon = len(features.lat), len(features.lon)
         if device is None:
@@ -224,91 +242,211 @@ class LargeAreaPredictor:
             raise RuntimeError("LargeAreaPredictor runs on the GPU only (no CPU fallback)")
         if any(v not in features for v in FEATURE_VARS) or lat < P or lon < P:
             return np.zeros((lat, lon), np.float32)         # no tile is ever valid (:173-175)
-        feats = torch.from_numpy(np.stack([_feature_array(features, v, lat, lon) for v in FEATURE_VARS]))
-        return self.predict_device(model, feats.to(device).contiguous()).cpu().numpy()
+        arrays = [_feature_array(features, v, lat, lon) for v in FEATURE_VARS]
+        P, S, nti, ntj, world, rank, bands = self._plan(lat, lon)
+        be = self.backend
+        model.eval()
+        engine, dt = be.make_engine(model)
+        wk = torch.from_numpy(self.create_gaussian_weight_kernel(P)).to(device)
+        lo_row, hi_row = bands[rank]
+        g0, g1 = lo_row * S, (hi_row - 1) * S + P            # grid rows this rank reads
+        acc = torch.zeros((g1 - g0, lon), dtype=torch.float32, device=device)
+        cnt = torch.zeros((g1 - g0, lon), dtype=torch.float32, device=device)
+        self._recv_strip(acc, cnt, bands, rank, S, P, lat, g0)
+        step = max(1, int(getattr(self.config, "HOST_BLOCK_TILE_ROWS", 8)))
+        blocks = [(a, min(a + step, hi_row)) for a in range(lo_row, hi_row, step)]
+        main = torch.cuda.current_stream(device)
+        copy = _copy_stream(device)
+        nvar = len(arrays)
+        max_rows = max((b - 1) * S + P - a * S for a, b in blocks)
+        stage = self._staging(nvar, max_rows, lon, device)     # two pinned blocks + two device blocks, re-used across calls
+        kept = []
+        pending = None
+        free_events = [None, None]                # the network passes that last read device block i
+        for k, blk in enumerate(blocks + [None]):          # block k is uploaded while block k-1 runs
+            nxt = None
+            if blk is not None:
+                a, b = blk
+                r0, r1 = a * S, (b - 1) * S + P
+                host, devb = stage[k % 2]
+                # (dense (nvar, rows, lon) views of the flat blocks: the kernels take one plane pitch of rows * lon)
+                hv = host.view(-1)[:nvar * (r1 - r0) * lon].view(nvar, r1 - r0, lon)
+                if free_events[k % 2] is not None:
+                    free_events[k % 2].synchronize()        # pinned + device block k%2 were last used two blocks ago
+                for v in range(nvar):                        # (multi-threaded copy into the pinned block)
+                    hv[v].copy_(torch.from_numpy(arrays[v][r0:r1]))
+                dv = devb.view(-1)[:nvar * (r1 - r0) * lon].view(nvar, r1 - r0, lon)
+                with torch.cuda.stream(copy):
+                    dv.copy_(hv, non_blocking=True)
+                    valid_d = be.valid_device(dv, P, S, b - a, ntj)
+                    valid_p = torch.empty(valid_d.shape, dtype=valid_d.dtype, pin_memory=True)
+                    valid_p.copy_(valid_d, non_blocking=True)
+                    ready = torch.cuda.Event()
+                    ready.record(copy)
+                nxt = (k, a, b, dv, valid_p, ready)
+            if pending is not None:
+                pk, pa, pb, pdv, pvalid, pready = pending
+                pready.synchronize()                          # waits for the copy stream only
+                main.wait_event(pready)
+                off = pa * S - g0
+                rows = (pb - 1) * S + P - pa * S
+                got = self._run_rows(engine, dt, wk, pdv, acc[off:off + rows], cnt[off:off + rows],
+                                     pvalid.numpy().astype(bool), pa * S)
+                if got is not None:
+                    kept.append(got)
+                done = torch.cuda.Event()
+                done.record(main)
+                free_events[pk % 2] = done
+            pending = nxt
+        self._send_strip(acc, cnt, bands, rank, S, P, lat, g0)
+        if self.keep_tile_predictions:
+            self.last_tile_predictions = (np.concatenate([k[0] for k in kept]) if kept else np.zeros((0, 2), np.int32),
+                                          np.concatenate([k[1] for k in kept]) if kept else np.zeros((0, P, P), np.float32))
+        return self._assemble(be.normalize(acc, cnt), bands, rank, world, S, lat, lon, g0, to_host=True)
 
     def predict_device(self, model, feats: torch.Tensor) -> torch.Tensor:
-        """feats: (4, lat, lon) fp32 on the device -> blended (lat, lon) fp32 map on every rank."""
-        import torch.distributed as dist
+        """feats: (4, lat, lon) fp32 on the device -> blended (lat, lon) fp32 map on every rank.  With several
+        ranks each one copies its band's rows out of the grid and works on that copy alone."""
         be = self.backend
-        P, S = int(self.config.PATCH_SIZE), int(self.config.STRIDE)
         nvar, lat, lon = feats.shape
         dev = feats.device
-        nti, ntj = (lat - P) // S + 1, (lon - P) // S + 1
-        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        rank = dist.get_rank() if world > 1 else 0
-        if world > nti:
-            raise ValueError(f"{world} ranks for {nti} tile rows: use at most one rank per tile row")
-        bands = band_partition(nti, world)
+        P, S, nti, ntj, world, rank, bands = self._plan(lat, lon)
         model.eval()
         engine, dt = be.make_engine(model)
         wk = torch.from_numpy(self.create_gaussian_weight_kernel(P)).to(dev)
+        lo_row, hi_row = bands[rank]
+        g0, g1 = lo_row * S, (hi_row - 1) * S + P
+        if world == 1:
+            band, g0, g1 = feats, 0, lat                     # (the rows below the last tile stay zero)
+        else:
+            band = feats[:, g0:g1].contiguous()
+        acc = torch.zeros((g1 - g0, lon), dtype=torch.float32, device=dev)
+        cnt = torch.zeros((g1 - g0, lon), dtype=torch.float32, device=dev)
+        self._recv_strip(acc, cnt, bands, rank, S, P, lat, g0)
+        kept = self._run_rows(engine, dt, wk, band, acc, cnt, None, g0)
+        self._send_strip(acc, cnt, bands, rank, S, P, lat, g0)
+        if self.keep_tile_predictions:
+            self.last_tile_predictions = kept
+        return self._assemble(be.normalize(acc, cnt), bands, rank, world, S, lat, lon, g0, to_host=False)
 
-        valid_h = be.valid(feats, P, S, nti, ntj)
+    def _run_rows(self, engine, dt, wk, feats, acc, cnt, valid_h, grid_row0):
+        """The reference's loop on one block of whole tile rows: feats (nvar, rows, lon) on the device; every valid
+        tile of the block is gathered, run through the network and ADDED to acc / cnt (rows, lon) in the reference's
+        order (lat-major).  acc / cnt may already hold the partial sums of the tiles above the block.  Returns the
+        kept tile predictions (grid positions, predictions) when asked for."""
+        be = self.backend
+        P, S = int(self.config.PATCH_SIZE), int(self.config.STRIDE)
+        nvar, rows, lon = feats.shape
+        nti, ntj = (rows - P) // S + 1, (lon - P) // S + 1
+        if valid_h is None:
+            valid_h = be.valid(feats, P, S, nti, ntj)
+        dev = feats.device
         slot_h = np.full(nti * ntj, -1, np.int32)
         slot_h[valid_h] = np.arange(int(valid_h.sum()), dtype=np.int32)
-        slot = torch.from_numpy(slot_h).to(dev)
         tiles = np.flatnonzero(valid_h)                      # lat-major, as the reference loops
+        if len(tiles) == 0:
+            return (np.zeros((0, 2), np.int32), np.zeros((0, P, P), np.float32)) if self.keep_tile_predictions else None
         pos_all = np.stack([(tiles // ntj) * S, (tiles % ntj) * S], 1).astype(np.int32)
-        pos_d = torch.from_numpy(pos_all).to(dev)
-
-        lo_row, hi_row = bands[rank]
-        mine = np.flatnonzero((tiles // ntj >= lo_row) & (tiles // ntj < hi_row))   # consecutive ids
-        acc = torch.zeros((lat, lon), dtype=torch.float32, device=dev)
-        cnt = torch.zeros((lat, lon), dtype=torch.float32, device=dev)
-
-        # the network on this rank's tiles: the expensive part, independent of the blend order
+        both = torch.from_numpy(np.concatenate([slot_h, pos_all.reshape(-1)]))
+        if dev.type == "cuda":
+            both = both.pin_memory().to(dev, non_blocking=True)
+        slot, pos_d = both[:nti * ntj], both[nti * ntj:].view(-1, 2)
+        # the network on the block's tiles: the expensive part, independent of the blend order.  Equal-sized
+        # launches (at most device_batch tiles each): no short last batch that would run the whole network for a
+        # handful of tiles
         preds = []
-        # equal-sized launches (at most device_batch tiles each): no short last batch that would run the whole
-        # network for a handful of tiles
-        nlaunch = max(1, -(-len(mine) // self.device_batch))
-        per_launch = max(1, -(-len(mine) // nlaunch))
-        for s in range(0, len(mine), per_launch):
-            ids = mine[s:s + per_launch]
-            out = engine(be.gather(feats, pos_d, int(ids[0]), len(ids), P, dt))
+        nlaunch = max(1, -(-len(tiles) // self.device_batch))
+        per_launch = max(1, -(-len(tiles) // nlaunch))
+        for s in range(0, len(tiles), per_launch):
+            n = min(per_launch, len(tiles) - s)
+            out = engine(be.gather(feats, pos_d, s, n, P, dt))
             if out.shape[1] != 1:
                 out = out[:, :1].contiguous()
-            preds.append((int(ids[0]), int(ids[-1]) + 1, out))
-
-        # blend.  Rows below lo_row*S may already hold tiles of the ranks above: take their
-        # partial sums first, add this band's tiles in order, hand the bottom strip on.
-        row0 = lo_row * S
-        row1 = min((hi_row - 1) * S + P, lat)
-        if rank > 0:
-            strip_end = min((bands[rank - 1][1] - 1) * S + P, lat)
-            if strip_end > row0:
-                buf = torch.empty((2, strip_end - row0, lon), dtype=torch.float32, device=dev)
-                dist.recv(buf, src=rank - 1)
-                acc[row0:strip_end] = buf[0]
-                cnt[row0:strip_end] = buf[1]
-                row1 = max(row1, strip_end)
+            preds.append((s, s + n, out))
         for t0, t1, out in preds:
             r0 = int(pos_all[t0, 0])
-            r1 = min(int(pos_all[t1 - 1, 0]) + P, lat)
+            r1 = min(int(pos_all[t1 - 1, 0]) + P, rows)
             be.accumulate(out, wk, slot, t0, t1, nti, ntj, P, S, acc, cnt, r0, r1)
-        if rank < world - 1:
-            nxt_row0 = hi_row * S
-            send_end = min((hi_row - 1) * S + P, lat)
-            if send_end > nxt_row0:
-                dist.send(torch.stack([acc[nxt_row0:send_end], cnt[nxt_row0:send_end]]).contiguous(),
-                          dst=rank + 1)
         if self.keep_tile_predictions:
-            kept = [o[:, 0].float().cpu().numpy() for _, _, o in preds]
-            ids = np.concatenate([np.arange(a, b) for a, b, _ in preds]) if preds else np.zeros(0, np.int64)
-            self.last_tile_predictions = (pos_all[ids], np.concatenate(kept) if kept else np.zeros((0, P, P), np.float32))
-        out_map = be.normalize(acc, cnt)
+            gpos = pos_all.copy()
+            gpos[:, 0] += grid_row0
+            return gpos, np.concatenate([o[:, 0].float().cpu().numpy() for _, _, o in preds])
+        return None
+
+    @staticmethod
+    def _recv_strip(acc, cnt, bands, rank, S, P, lat, g0):
+        """Rows at the top of this band already hold tiles of the rank above: take its partial sums first."""
+        import torch.distributed as dist
+        if rank == 0:
+            return
+        strip_end = min((bands[rank - 1][1] - 1) * S + P, lat)
+        if strip_end > g0:
+            buf = torch.empty((2, strip_end - g0, acc.shape[1]), dtype=torch.float32, device=acc.device)
+            dist.recv(buf, src=rank - 1)
+            acc[:strip_end - g0] = buf[0]
+            cnt[:strip_end - g0] = buf[1]
+
+    @staticmethod
+    def _send_strip(acc, cnt, bands, rank, S, P, lat, g0):
+        import torch.distributed as dist
+        if rank >= len(bands) - 1:
+            return
+        hi_row = bands[rank][1]
+        nxt_row0 = hi_row * S
+        send_end = min((hi_row - 1) * S + P, lat)
+        if send_end > nxt_row0:
+            dist.send(torch.stack([acc[nxt_row0 - g0:send_end - g0], cnt[nxt_row0 - g0:send_end - g0]]).contiguous(),
+                      dst=rank + 1)
+
+    def _assemble(self, band_map, bands, rank, world, S, lat, lon, g0, to_host):
+        """band_map: the normalised rows [g0, ...) of this rank.  Rank r owns the rows from its band's first row to
+        the next band's first row (the last rank: to the end of the grid, rows no tile covers are zero); the map
+        is assembled by an all-gather of the owned rows (padded to the tallest band)."""
+        import torch.distributed as dist
+        dev = band_map.device
         if world == 1:
-            return out_map
-        # rank r owns the rows from its band's first row to the next band's first row (last: to the end);
-        # the map is assembled by an all-gather of the owned rows (padded to the tallest band)
-        owned = [(bands[r][0] * S if r > 0 else 0, bands[r + 1][0] * S if r < world - 1 else lat) for r in range(world)]
-        tall = max(b - a for a, b in owned)
-        own0, own1 = owned[rank]
-        mine = torch.zeros((tall, lon), dtype=torch.float32, device=dev)
-        mine[:own1 - own0] = out_map[own0:own1]
-        parts = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(parts, mine)
-        full = torch.empty((lat, lon), dtype=torch.float32, device=dev)
-        for (a, b), part in zip(owned, parts):
-            full[a:b] = part[:b - a]
-        return full
+            if band_map.shape[0] == lat:
+                full = band_map
+            else:
+                full = torch.zeros((lat, lon), dtype=torch.float32, device=dev)
+                full[g0:g0 + band_map.shape[0]] = band_map
+        else:
+            owned = [(bands[r][0] * S if r > 0 else 0, bands[r + 1][0] * S if r < world - 1 else lat) for r in range(world)]
+            tall = max(b - a for a, b in owned)
+            own0, own1 = owned[rank]
+            mine = torch.zeros((tall, lon), dtype=torch.float32, device=dev)
+            n = min(own1, g0 + band_map.shape[0]) - own0
+            mine[:n] = band_map[own0 - g0:own0 - g0 + n]
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine)
+            full = torch.empty((lat, lon), dtype=torch.float32, device=dev)
+            for (a, b), part in zip(owned, parts):
+                full[a:b] = part[:b - a]
+        if not to_host:
+            return full
+        out = torch.empty((lat, lon), dtype=torch.float32, pin_memory=True)
+        out.copy_(full, non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()
+        return out.numpy()
+
+    def _staging(self, nvar, rows, lon, device):
+        key = (nvar, rows, lon, str(device))
+        hit = getattr(self, "_stage", None)
+        if hit is None or hit[0] != key:
+            bufs = [(torch.empty((nvar, rows, lon), dtype=torch.float32, pin_memory=True),
+                     torch.empty((nvar, rows, lon), dtype=torch.float32, device=device)) for _ in range(2)]
+            hit = self._stage = (key, bufs)
+        return hit[1]
+
+
+_COPY_STREAMS = {}
+
+
+def _copy_stream(device):
+    key = torch.device(device).index
+    if key is None:
+        key = torch.cuda.current_device()
+    st = _COPY_STREAMS.get(key)
+    if st is None:
+        st = _COPY_STREAMS[key] = torch.cuda.Stream(device=key)
+    return st
