@@ -125,6 +125,19 @@ int unetk_linear_fwd(const void* x, int ldx, const void* wpacked, void* out, int
                      int ldr, const float* resid_keep, int64_t tok_per_sample, const void* gelu_grad_of, int ldaux,
                      unetk_stream_t stream);
 
+/* The MLP branch of a Swin block in one launch (swin_unet_model.py:372 with :296-303 and nn.LayerNorm):
+ *   ln = LayerNorm(x) (gamma, beta, eps; mean / rstd per token kept for the backward),
+ *   hpre = ln @ w1^T + b1,  hact = GELU(hpre as stored),  out = x + keep[t / tok_per_sample] * (hact @ w2^T + b2).
+ * x, ln, out: dense [M][C]; hpre, hact: dense [M][4C] (hact nullable: then GELU(hpre) is not stored).  w1: the
+ * (4C, C) weight packed as for unetk_conv_fwd with ks = 1 and channel block 64; w2: the (C, 4C) weight packed
+ * with channel block 96.  bfloat16, C = 96 or 192 (the stages whose hidden tensor is bound by HBM): ask
+ * unetk_swin_mlp_supported; other shapes use unetk_layernorm_fwd + unetk_linear_fwd + unetk_gelu_fwd. */
+int unetk_swin_mlp_supported(int64_t M, int C, int dtype);
+int unetk_swin_mlp_fwd(const void* x, const float* gamma, const float* beta, float eps, const void* w1_packed64,
+                       const float* b1, const void* w2_packed96, const float* b2, const float* keep,
+                       int64_t tok_per_sample, void* ln, float* mean, float* rstd, void* hpre, void* hact, void* out,
+                       int64_t M, int C, int dtype, unetk_stream_t stream);
+
 /* Weight and bias gradient of a token linear (autograd of the products above):
  *   dw[n][k] (+)= sum_t dy[t][n] * x[t][k],   dbias[n] (+)= sum_t dy[t][n]  (dbias nullable).
  * bfloat16 operands, fp32 results; workspace (fp32 partial tiles of the token ranges, summed in a fixed

@@ -629,3 +629,45 @@ def test_swin_bf16_loss_curve_tracks_fp32():
     assert f32[-1] < 0.05 * f32[0] and b16[-1] < 0.05 * b16[0]
     assert self_dev.max() < 0.03, self_dev
     assert dev.max() < 0.10 and dev.mean() < 0.04, dev
+
+
+@pytest.mark.parametrize("C,B,H,Wd", [(96, 2, 16, 24), (96, 3, 9, 7), (192, 2, 8, 16), (192, 1, 5, 3), (96, 4, 64, 64)])
+def test_fused_mlp_branch_matches_separate_launches(C, B, H, Wd):
+    """The one-launch MLP branch of a Swin block (LayerNorm, fc1, GELU, fc2, residual + DropPath scale) against the
+    four separate launches it replaces and against torch: LayerNorm output and statistics bit for bit (the same
+    arithmetic lane for lane), pre-activation bit for bit (the same products in the same order), GELU and output to
+    bf16 rounding (the stand-alone GELU pass evaluates erf through the library, the fused epilogue through a
+    polynomial that is 1.5e-7 away).  Ragged token counts: tiles with rows past the end."""
+    from unet_amd import ops
+    g = torch.Generator().manual_seed(C + H)
+    dt = torch.bfloat16
+    x = (torch.randn(B, H, Wd, C, generator=g) * 1.5 + 0.3).to(dt).cuda()
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.1).cuda()
+    w1 = (torch.randn(4 * C, C, generator=g) * C ** -0.5).cuda()
+    b1 = (torch.randn(4 * C, generator=g) * 0.1).cuda()
+    w2 = (torch.randn(C, 4 * C, generator=g) * (4 * C) ** -0.5).cuda()
+    b2 = (torch.randn(C, generator=g) * 0.1).cuda()
+    keep = torch.tensor([1 / 0.9, 0.0, 1 / 0.9, 1 / 0.9][:B]).cuda()
+    assert ops.swin_mlp_supported(x)
+    p1, p2 = ops.pack_many([(w1, "bn64"), (w2, False)], dt)
+    assert p1.bn == 64 and p2.bn == 96
+    out, ln, mean, rstd, hpre, hact = ops.swin_mlp_fwd(x, gamma, beta, 1e-5, p1, b1, p2, b2, keep=keep)
+    # the separate launches
+    ln0, mean0, rstd0 = ops.layernorm_fwd(x, gamma, beta, 1e-5)
+    pw1, pw2 = ops.PackedConv(w1, dt), ops.PackedConv(w2, dt)
+    hpre0 = ops.linear_fwd(ln0, pw1, bias=b1)
+    hact0 = ops.gelu_fwd(hpre0)
+    out0 = ops.linear_fwd(hact0, pw2, bias=b2, resid=x, resid_keep=keep)
+    eq = lambda a, b: torch.equal(a.view(torch.int16), b.view(torch.int16))
+    assert eq(ln, ln0) and torch.equal(mean, mean0) and torch.equal(rstd, rstd0)
+    assert eq(hpre, hpre0)
+    assert rel(hact, hact0) < 2e-3 and rel(out, out0) < 4e-3
+    # without the stored GELU: the same pre-activation and output
+    out_b, _, _, _, hpre_b, none = ops.swin_mlp_fwd(x, gamma, beta, 1e-5, p1, b1, p2, b2, keep=keep, want_act=False)
+    assert none is None and eq(out_b, out) and eq(hpre_b, hpre)
+    # torch, fp32 on the bf16-rounded inputs
+    xf = x.float().cpu()
+    lnr = F.layer_norm(xf, (C,), gamma.cpu(), beta.cpu())
+    h = F.linear(lnr, w1.to(dt).float().cpu(), b1.cpu())
+    ref = xf + keep.cpu().view(B, 1, 1, 1) * F.linear(F.gelu(h), w2.to(dt).float().cpu(), b2.cpu())
+    assert rel(hpre, h) < 1e-2 and rel(out, ref) < 1e-2

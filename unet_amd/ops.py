@@ -101,7 +101,8 @@ def pack_many(weights, dt):
     """Pack several weights with ONE launch.  weights: list of (fp32 GPU tensor (Co, Ci[, k, k]), transpose);
     returns the list of PackedConv (views of one buffer).  transpose may also be "convt" / "convt_t": the tensor is
     a ConvTranspose2d(k=2, s=2) weight (Cin, up, 2, 2), packed as the (4*up, Cin) matrix whose row
-    (ky*2+kx)*up + co is weight[:, co, ky, kx] (forward form) or as its data-gradient form.  The device-side job
+    (ky*2+kx)*up + co is weight[:, co, ky, kx] (forward form) or as its data-gradient form; or "bn64": the forward
+    form with 64-channel blocks whatever the width (the fused MLP kernel's fc1 operand).  The device-side job
     table depends on the source addresses and shapes only, and parameters do not move: a training step re-uses it
     (a new one goes up from pinned memory without blocking the host)."""
     if not weights:
@@ -120,6 +121,9 @@ def pack_many(weights, dt):
     metas, srcs, rows, off = [], [], [], 0
     for w, transpose in weights:
         _require_cuda(w, "weight")
+        force_bn = 0
+        if transpose == "bn64":
+            force_bn, transpose = 64, False
         convt = isinstance(transpose, str)
         if convt:
             if transpose not in ("convt", "convt_t") or w.dim() != 4 or tuple(w.shape[2:]) != (2, 2):
@@ -135,7 +139,9 @@ def pack_many(weights, dt):
         else:
             Co, Ci, ks, _ = w.shape
         pCo, pCi = (Ci, Co) if transpose else (Co, Ci)
-        bn = lib.unetk_conv_pick_bn(pCo)
+        bn = force_bn or lib.unetk_conv_pick_bn(pCo)
+        if pCo % bn and force_bn:
+            raise ValueError(f"pack_many: {pCo} output channels are not whole blocks of {bn}")
         n = lib.unetk_conv_packed_elems(pCo, pCi, ks, bn, dtype_code(dt))
         metas.append((pCo, pCi, ks, bn, off, n))
         srcs.append(w)
@@ -672,6 +678,34 @@ def channel_sum(x, C=None):
     out = torch.empty(C, dtype=torch.float32, device=x.device)
     call("unetk_channel_sum", ptr(x), ld, ntok, C, ptr(out), ptr(partials), dtype_code(x.dtype), stream())
     return out
+
+
+def swin_mlp_supported(x) -> bool:
+    """Whether the one-launch MLP branch takes these tokens (bfloat16, dense, 96 or 192 channels)."""
+    C = x.shape[-1]
+    return bool(x.dtype == torch.bfloat16 and x.is_contiguous() and
+                _lib.load().unetk_swin_mlp_supported(x.numel() // C, C, dtype_code(x.dtype)))
+
+
+def swin_mlp_fwd(x, gamma, beta, eps, w1_pack64: PackedConv, b1, w2_pack96: PackedConv, b2, keep=None, want_act=True):
+    """out = x + keep[sample] * fc2(GELU(fc1(LayerNorm(x)))) in one launch.  Returns (out, ln, mean, rstd, hpre,
+    hact or None): everything the backward pass of the branch reads."""
+    C = x.shape[-1]
+    M = x.numel() // C
+    if w1_pack64.bn != 64 or w2_pack96.bn != 96 or (w1_pack64.Co, w1_pack64.Ci) != (4 * C, C) or \
+            (w2_pack96.Co, w2_pack96.Ci) != (C, 4 * C):
+        raise ValueError("swin_mlp_fwd: fc1 must be packed in 64-channel blocks, fc2 in 96-channel blocks")
+    dev = x.device
+    ln = torch.empty_like(x)
+    out = torch.empty_like(x)
+    mean = torch.empty(M, dtype=torch.float32, device=dev)
+    rstd = torch.empty(M, dtype=torch.float32, device=dev)
+    hpre = torch.empty(x.shape[:-1] + (4 * C,), dtype=x.dtype, device=dev)
+    hact = torch.empty_like(hpre) if want_act else None
+    call("unetk_swin_mlp_fwd", ptr(x), ptr(gamma), ptr(beta), float(eps), ptr(w1_pack64.data), ptr(b1),
+         ptr(w2_pack96.data), ptr(b2), ptr(keep), M // x.shape[0], ptr(ln), ptr(mean), ptr(rstd), ptr(hpre), ptr(hact),
+         ptr(out), M, C, dtype_code(x.dtype), stream())
+    return out, ln, mean, rstd, hpre, hact
 
 
 def gelu_fwd(x):

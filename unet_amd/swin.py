@@ -250,9 +250,18 @@ class _Ctx:
         wt = [m.weight for m in model.__dict__.get("_convt_modules", ())
               if m.weight.is_cuda and m.weight.dtype == torch.float32 and m.weight.is_contiguous()]
         forms = (False, True) if training else (False,)
+        # fc1 of the blocks whose MLP branch runs as one launch: 64-channel blocks
+        w64 = []
+        if FUSED_MLP and dt == torch.bfloat16:
+            w64 = [blk.mlp[0].weight for layer in getattr(model, "layers", ()) for blk in layer.blocks
+                   if blk.dim in (96, 192) and blk.mlp[0].weight.shape == (4 * blk.dim, blk.dim) and
+                   any(blk.mlp[0].weight is w for w in ws)]
         packs = ops.pack_many([(w, tr) for tr in forms for w in ws] +
-                              [(w, "convt_t" if tr else "convt") for tr in forms for w in wt], dt)
+                              [(w, "convt_t" if tr else "convt") for tr in forms for w in wt] +
+                              [(w, "bn64") for w in w64], dt)
         self.pool = {}
+        for j, w in enumerate(w64):
+            self.pool[(w.data_ptr(), "bn64")] = (packs[len(forms) * (len(ws) + len(wt)) + j], w._version)
         for i, tr in enumerate(forms):
             for j, w in enumerate(ws):
                 self.pool[(w.data_ptr(), tr)] = (packs[i * len(ws) + j], w.shape[0], w.shape[1],
@@ -273,6 +282,13 @@ class _Ctx:
         w2 = w.permute(2, 3, 1, 0).reshape(4 * up, Cin)       # [(ky,kx,co)][ci]
         return ops.PackedConv(w2, self.dt, transpose=transpose)
 
+    def packed64(self, w):
+        """fc1 of a fused MLP branch in 64-channel blocks, or None when this step did not pack it."""
+        hit = self.pool.get((w.data_ptr(), "bn64"))
+        if hit is None or hit[1] != w._version:
+            return None
+        return hit[0]
+
     def packed(self, w, transpose=False):
         hit = self.pool.get((w.data_ptr(), bool(transpose)))
         ks = 1 if w.dim() == 2 else w.shape[2]
@@ -292,6 +308,12 @@ class _Ctx:
 OVERLAP_WGRAD = os.environ.get("UNETK_SWIN_OVERLAP_WGRAD", "1") != "0"
 DEFER_LN_SUMS = os.environ.get("UNETK_SWIN_DEFER_LN_SUMS", "1") != "0"     # LayerNorm dgamma / dbeta sums: one launch at the end of the backward
 CONVT_BWD_GATHER = os.environ.get("UNETK_SWIN_CONVT_BWD_GATHER", "1") != "0"   # ConvTranspose data gradient reads the gradient image in place
+# The MLP branch of the 96- and 192-channel blocks as ONE launch (LayerNorm, fc1, GELU, fc2, residual): the hidden
+# tensor no longer travels through HBM between four kernels.  With FUSED_MLP_SAVE_ACT off the GELU output is not
+# stored either: the backward pass recomputes it from the pre-activation next to the weight gradient that reads it
+# (on that gradient's stream, off the data-gradient chain).
+FUSED_MLP = os.environ.get("UNETK_SWIN_FUSED_MLP", "1") != "0"
+FUSED_MLP_SAVE_ACT = os.environ.get("UNETK_SWIN_MLP_SAVE_ACT", "1") != "0"
 _SIDE_STREAMS = {}
 
 
@@ -345,9 +367,14 @@ def _linear(x, w, b, cx, act=0, resid=None, keep=None, out=None, out2=False):
     return _linear_launch(x, cx.packed(w), shift=b, act=act, resid=resid, resid_keep=keep, out=out, out2=out2)
 
 
-def _linear_bwd(x, dy, w, cx, grads, wname, bname, need_dx=True, gelu_grad_of=None):
+def _linear_bwd(x, dy, w, cx, grads, wname, bname, need_dx=True, gelu_grad_of=None, x_from=None):
+    """x_from: x is not stored; it is GELU(x_from), recomputed on the stream of the weight gradient that reads it."""
     Co, Ci = w.shape[0], w.shape[1]
-    dw, db = _on_side(cx, lambda: ops.linear_wgrad(x, dy, Ci, Co, want_bias=bname is not None), x, dy)
+    if x is None:
+        dw, db = _on_side(cx, lambda: ops.linear_wgrad(ops.gelu_fwd(x_from), dy, Ci, Co, want_bias=bname is not None),
+                          x_from, dy)
+    else:
+        dw, db = _on_side(cx, lambda: ops.linear_wgrad(x, dy, Ci, Co, want_bias=bname is not None), x, dy)
     if bname is not None:
         grads[bname] = db
     grads[wname] = dw.view(w.shape)
@@ -389,11 +416,19 @@ def _block_fwd(blk, pre, x, keep1, keep2, cx, save):
     else:
         pr = _linear(att, a.proj.weight, a.proj.bias, cx)
         x1 = ops.scale_sample(pr[:, :H, :W].contiguous(), keep1, x)
-    ln2, m2, r2 = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
-    # (GELU stays its own pass: fc1 writing both tensors is bound by the same two writes, measured equal or slower)
-    hpre = _linear(ln2, blk.mlp[0].weight, blk.mlp[0].bias, cx)
-    hact = ops.gelu_fwd(hpre)
-    x2 = _linear(hact, blk.mlp[3].weight, blk.mlp[3].bias, cx, resid=x1, keep=keep2)
+    p64 = cx.packed64(blk.mlp[0].weight) if FUSED_MLP else None
+    p96 = cx.packed(blk.mlp[3].weight) if p64 is not None else None
+    if p64 is not None and p96.bn == 96 and blk.mlp[0].bias is not None and blk.mlp[3].bias is not None and \
+            ops.swin_mlp_supported(x1):
+        x2, ln2, m2, r2, hpre, hact = ops.swin_mlp_fwd(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, p64,
+                                                        blk.mlp[0].bias, p96, blk.mlp[3].bias, keep=keep2,
+                                                        want_act=FUSED_MLP_SAVE_ACT or save is None)
+    else:
+        ln2, m2, r2 = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+        # (GELU stays its own pass: fc1 writing both tensors is bound by the same two writes, measured equal or slower)
+        hpre = _linear(ln2, blk.mlp[0].weight, blk.mlp[0].bias, cx)
+        hact = ops.gelu_fwd(hpre)
+        x2 = _linear(hact, blk.mlp[3].weight, blk.mlp[3].bias, cx, resid=x1, keep=keep2)
     if save is not None:
         save.append(("block", blk, pre, (x, m1, r1, ln1p, qkv, att, x1, m2, r2, ln2, hpre, hact, keep1, keep2,
                                           (H, W, He, We))))
@@ -419,9 +454,9 @@ def _block_bwd(blk, pre, ctx, dx2, cx, grads, db2=None, keep_next=None):
     # large (it saves one write and one read of it); on the small late stages the separate pass is as fast
     if hpre.numel() >= _FUSE_GELU_BWD_ELEMS:
         dhp = _linear_bwd(hact, db, blk.mlp[3].weight, cx, grads, pre + "mlp.3.weight", pre + "mlp.3.bias",
-                          gelu_grad_of=hpre)
+                          gelu_grad_of=hpre, x_from=hpre)
     else:
-        dh = _linear_bwd(hact, db, blk.mlp[3].weight, cx, grads, pre + "mlp.3.weight", pre + "mlp.3.bias")
+        dh = _linear_bwd(hact, db, blk.mlp[3].weight, cx, grads, pre + "mlp.3.weight", pre + "mlp.3.bias", x_from=hpre)
         dhp = ops.gelu_bwd(dh, hpre)
     dln2 = _linear_bwd(ln2, dhp, blk.mlp[0].weight, cx, grads, pre + "mlp.0.weight", pre + "mlp.0.bias")
     res = ops.layernorm_bwd(dln2, x1, blk.norm2.weight, m2, r2, add=dx2, defer=cx.sums,
