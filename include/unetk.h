@@ -138,6 +138,22 @@ int unetk_swin_mlp_fwd(const void* x, const float* gamma, const float* beta, flo
                        int64_t tok_per_sample, void* ln, float* mean, float* rstd, void* hpre, void* hact, void* out,
                        int64_t M, int C, int dtype, unetk_stream_t stream);
 
+/* The data-gradient chain of that branch in one launch (autograd of the lines above): dy = gradient of the
+ * branch's output with its DropPath factor applied, [M][C];
+ *   dhp = (dy @ w2) * GELU'(hpre)                      [M][4C], stored: the weight gradient of fc1 reads it
+ *   dx  = LayerNorm'(dhp @ w1; x, mean, rstd, gamma) + add     (add nullable)
+ *   dx_scaled = dx * keep[t / tok_per_sample]          (both nullable together)
+ *   partials[row][0][c], [row][1][c] = this workgroup's sums over tokens of d ln * xhat and d ln: their column
+ *   sums over the unetk_swin_mlp_bwd_rows(M, C) rows are the LayerNorm's weight and bias gradients
+ *   (unetk_partial_sums_batched).
+ * w2t: the (C, 4C) fc2 weight in its data-gradient pack (transpose = 1) with channel block 64; w1t: the (4C, C)
+ * fc1 weight in its data-gradient pack with channel block 96.  Shapes as unetk_swin_mlp_supported. */
+int unetk_swin_mlp_bwd_rows(int64_t M, int C);
+int unetk_swin_mlp_bwd(const void* dy, const void* hpre, const void* w2t_packed64, const void* w1t_packed96,
+                       const void* x, const float* mean, const float* rstd, const float* gamma, const void* add,
+                       const float* keep, int64_t tok_per_sample, void* dhp, void* dx, void* dx_scaled,
+                       float* partials, int64_t M, int C, int dtype, unetk_stream_t stream);
+
 /* Weight and bias gradient of a token linear (autograd of the products above):
  *   dw[n][k] (+)= sum_t dy[t][n] * x[t][k],   dbias[n] (+)= sum_t dy[t][n]  (dbias nullable).
  * bfloat16 operands, fp32 results; workspace (fp32 partial tiles of the token ranges, summed in a fixed

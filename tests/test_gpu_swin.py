@@ -671,3 +671,54 @@ def test_fused_mlp_branch_matches_separate_launches(C, B, H, Wd):
     h = F.linear(lnr, w1.to(dt).float().cpu(), b1.cpu())
     ref = xf + keep.cpu().view(B, 1, 1, 1) * F.linear(F.gelu(h), w2.to(dt).float().cpu(), b2.cpu())
     assert rel(hpre, h) < 1e-2 and rel(out, ref) < 1e-2
+
+
+@pytest.mark.parametrize("C,B,H,Wd", [(96, 2, 16, 24), (96, 3, 9, 7), (192, 2, 8, 16), (192, 1, 5, 3), (96, 4, 64, 64)])
+def test_fused_mlp_backward_matches_separate_launches(C, B, H, Wd):
+    """The data-gradient chain of the MLP branch in one launch (fc2's data gradient, GELU', fc1's data gradient,
+    LayerNorm backward with the residual gradient added, the DropPath-scaled copy, the LayerNorm parameter-gradient
+    partials) against the separate launches and against torch autograd.  The hidden gradient agrees to bf16
+    rounding (same products, GELU' through the hardware reciprocal); the LayerNorm backward sums a token's channels
+    in another order."""
+    from unet_amd import ops
+    g = torch.Generator().manual_seed(C + H + 1)
+    dt = torch.bfloat16
+    x = (torch.randn(B, H, Wd, C, generator=g) * 1.5 + 0.3).to(dt).cuda()
+    dy = torch.randn(B, H, Wd, C, generator=g).to(dt).cuda()
+    add = torch.randn(B, H, Wd, C, generator=g).to(dt).cuda()
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.1).cuda()
+    w1 = (torch.randn(4 * C, C, generator=g) * C ** -0.5).cuda()
+    b1 = (torch.randn(4 * C, generator=g) * 0.1).cuda()
+    w2 = (torch.randn(C, 4 * C, generator=g) * (4 * C) ** -0.5).cuda()
+    keep = torch.tensor([1 / 0.9, 0.0, 1 / 0.9, 1 / 0.9][:B]).cuda()
+    ln, mean, rstd = ops.layernorm_fwd(x, gamma, beta, 1e-5)
+    hpre = ops.linear_fwd(ln, ops.PackedConv(w1, dt), bias=b1)
+    p2t, p1t = ops.pack_many([(w2, "bn64_t"), (w1, True)], dt)
+    assert p2t.bn == 64 and p1t.bn == 96
+    later = ops.DeferredSums()
+    dhp, dx, dg, db, dxs = ops.swin_mlp_bwd(dy, hpre, p2t, p1t, x, mean, rstd, gamma, add, later, scale_next=(keep, H * Wd))
+    later.flush()
+    # the separate launches
+    dhp0 = ops.linear_fwd(dy, ops.PackedConv(w2, dt, transpose=True), gelu_grad_of=hpre)
+    dln0 = ops.linear_fwd(dhp0, ops.PackedConv(w1, dt, transpose=True))
+    dx0, dg0, db0 = ops.layernorm_bwd(dln0, x, gamma, mean, rstd, add=add)
+    assert rel(dhp, dhp0) < 2e-3
+    assert rel(dx, dx0) < 4e-3 and rel(dg, dg0) < 4e-3 and rel(db, db0) < 4e-3
+    assert torch.equal(dxs.view(torch.int16), ops.scale_sample(dx, keep).view(torch.int16))
+    # without the scaled copy, without the residual gradient
+    later = ops.DeferredSums()
+    dhp_b, dx_b, _, _, none = ops.swin_mlp_bwd(dy, hpre, p2t, p1t, x, mean, rstd, gamma, None, later)
+    later.flush()
+    assert none is None and torch.equal(dhp_b.view(torch.int16), dhp.view(torch.int16))
+    assert rel(dx_b.float() + add.float(), dx0) < 8e-3
+    # torch autograd in fp32 on the bf16-rounded operands
+    xr = x.float().cpu().requires_grad_(True)
+    gr, br = gamma.cpu().clone().requires_grad_(True), beta.cpu().clone().requires_grad_(True)
+    h = F.linear(F.layer_norm(xr, (C,), gr, br), w1.to(dt).float().cpu(), b1.cpu())
+    out = F.linear(F.gelu(h), w2.to(dt).float().cpu())
+    h.retain_grad()
+    out.backward(dy.float().cpu())
+    assert rel(dhp, h.grad) < 1.5e-2
+    assert rel(dx, xr.grad + add.float().cpu()) < 1.5e-2 and rel(dg, gr.grad) < 1.5e-2 and rel(db, br.grad) < 1.5e-2
+    with pytest.raises(ValueError):
+        ops.swin_mlp_bwd(dy, hpre, p1t, p1t, x, mean, rstd, gamma, add, ops.DeferredSums())

@@ -51,6 +51,8 @@ _SIGNATURES = {
     "unetk_linear_fwd": (I, [P, I, P, P, I, P, I, L, I, I, I, I, P, I, P, I, P, L, P, I, P]),
     "unetk_swin_mlp_supported": (I, [L, I, I]),
     "unetk_swin_mlp_fwd": (I, [P, P, P, F, P, P, P, P, P, L, P, P, P, P, P, P, L, I, I, P]),
+    "unetk_swin_mlp_bwd_rows": (I, [L, I]),
+    "unetk_swin_mlp_bwd": (I, [P, P, P, P, P, P, P, P, P, P, L, P, P, P, P, L, I, I, P]),
     "unetk_token_wgrad_supported": (I, [L, I, I, I]),
     "unetk_token_wgrad_workspace_bytes": (L, [L, I, I]),
     "unetk_token_wgrad": (I, [P, I, P, I, P, P, L, I, I, I, P, L, I, P]),

@@ -102,7 +102,8 @@ def pack_many(weights, dt):
     returns the list of PackedConv (views of one buffer).  transpose may also be "convt" / "convt_t": the tensor is
     a ConvTranspose2d(k=2, s=2) weight (Cin, up, 2, 2), packed as the (4*up, Cin) matrix whose row
     (ky*2+kx)*up + co is weight[:, co, ky, kx] (forward form) or as its data-gradient form; or "bn64": the forward
-    form with 64-channel blocks whatever the width (the fused MLP kernel's fc1 operand).  The device-side job
+    form with 64-channel blocks whatever the width (the fused MLP kernel's fc1 operand), "bn64_t": the data-gradient
+    form with 64-channel blocks.  The device-side job
     table depends on the source addresses and shapes only, and parameters do not move: a training step re-uses it
     (a new one goes up from pinned memory without blocking the host)."""
     if not weights:
@@ -122,8 +123,8 @@ def pack_many(weights, dt):
     for w, transpose in weights:
         _require_cuda(w, "weight")
         force_bn = 0
-        if transpose == "bn64":
-            force_bn, transpose = 64, False
+        if transpose in ("bn64", "bn64_t"):
+            force_bn, transpose = 64, transpose == "bn64_t"
         convt = isinstance(transpose, str)
         if convt:
             if transpose not in ("convt", "convt_t") or w.dim() != 4 or tuple(w.shape[2:]) != (2, 2):
@@ -706,6 +707,31 @@ def swin_mlp_fwd(x, gamma, beta, eps, w1_pack64: PackedConv, b1, w2_pack96: Pack
          ptr(w2_pack96.data), ptr(b2), ptr(keep), M // x.shape[0], ptr(ln), ptr(mean), ptr(rstd), ptr(hpre), ptr(hact),
          ptr(out), M, C, dtype_code(x.dtype), stream())
     return out, ln, mean, rstd, hpre, hact
+
+
+def swin_mlp_bwd(dy, hpre, w2t_pack64: PackedConv, w1t_pack96: PackedConv, x, mean, rstd, gamma, add, defer,
+                 scale_next=None):
+    """The data-gradient chain of the MLP branch in one launch: returns (dhp, dx, dgamma, dbeta, dx_scaled or None).
+    dgamma / dbeta are filled by ``defer.flush()`` (a DeferredSums).  scale_next = (keep (B,), tokens per sample)."""
+    C = x.shape[-1]
+    M = x.numel() // C
+    if w2t_pack64.bn != 64 or w1t_pack96.bn != 96 or (w2t_pack64.Co, w2t_pack64.Ci) != (4 * C, C) or \
+            (w1t_pack96.Co, w1t_pack96.Ci) != (C, 4 * C):
+        raise ValueError("swin_mlp_bwd: fc2 must be packed transposed in 64-channel blocks, fc1 transposed in 96-channel blocks")
+    dev = x.device
+    rows = _lib.load().unetk_swin_mlp_bwd_rows(M, C)
+    partials = torch.empty((rows, 2, C), dtype=torch.float32, device=dev)
+    dg = torch.empty(C, dtype=torch.float32, device=dev)
+    db = torch.empty(C, dtype=torch.float32, device=dev)
+    dhp = torch.empty_like(hpre)
+    dx = torch.empty_like(x)
+    keep, tps = (scale_next if scale_next is not None else (None, 1))
+    dxs = torch.empty_like(x) if keep is not None else None
+    call("unetk_swin_mlp_bwd", ptr(dy), ptr(hpre), ptr(w2t_pack64.data), ptr(w1t_pack96.data), ptr(x), ptr(mean),
+         ptr(rstd), ptr(gamma), ptr(add), ptr(keep), tps, ptr(dhp), ptr(dx), ptr(dxs), ptr(partials), M, C,
+         dtype_code(x.dtype), stream())
+    defer.add(partials, rows, C, dg, db)
+    return dhp, dx, dg, db, dxs
 
 
 def gelu_fwd(x):

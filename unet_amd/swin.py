@@ -256,12 +256,20 @@ class _Ctx:
             w64 = [blk.mlp[0].weight for layer in getattr(model, "layers", ()) for blk in layer.blocks
                    if blk.dim in (96, 192) and blk.mlp[0].weight.shape == (4 * blk.dim, blk.dim) and
                    any(blk.mlp[0].weight is w for w in ws)]
+        # ... and, for the backward pass of that launch, fc2 in its data-gradient form with 64-channel blocks
+        w64t = []
+        if w64 and training and FUSED_MLP_BWD:
+            w64t = [blk.mlp[3].weight for layer in model.layers for blk in layer.blocks
+                    if any(blk.mlp[0].weight is w for w in w64)]
         packs = ops.pack_many([(w, tr) for tr in forms for w in ws] +
                               [(w, "convt_t" if tr else "convt") for tr in forms for w in wt] +
-                              [(w, "bn64") for w in w64], dt)
+                              [(w, "bn64") for w in w64] + [(w, "bn64_t") for w in w64t], dt)
         self.pool = {}
+        base = len(forms) * (len(ws) + len(wt))
         for j, w in enumerate(w64):
-            self.pool[(w.data_ptr(), "bn64")] = (packs[len(forms) * (len(ws) + len(wt)) + j], w._version)
+            self.pool[(w.data_ptr(), "bn64")] = (packs[base + j], w._version)
+        for j, w in enumerate(w64t):
+            self.pool[(w.data_ptr(), "bn64_t")] = (packs[base + len(w64) + j], w._version)
         for i, tr in enumerate(forms):
             for j, w in enumerate(ws):
                 self.pool[(w.data_ptr(), tr)] = (packs[i * len(ws) + j], w.shape[0], w.shape[1],
@@ -282,9 +290,10 @@ class _Ctx:
         w2 = w.permute(2, 3, 1, 0).reshape(4 * up, Cin)       # [(ky,kx,co)][ci]
         return ops.PackedConv(w2, self.dt, transpose=transpose)
 
-    def packed64(self, w):
-        """fc1 of a fused MLP branch in 64-channel blocks, or None when this step did not pack it."""
-        hit = self.pool.get((w.data_ptr(), "bn64"))
+    def packed64(self, w, form="bn64"):
+        """fc1 of a fused MLP branch in 64-channel blocks (form "bn64_t": fc2 in its data-gradient form), or None
+        when this step did not pack it."""
+        hit = self.pool.get((w.data_ptr(), form))
         if hit is None or hit[1] != w._version:
             return None
         return hit[0]
@@ -314,6 +323,8 @@ CONVT_BWD_GATHER = os.environ.get("UNETK_SWIN_CONVT_BWD_GATHER", "1") != "0"   #
 # (on that gradient's stream, off the data-gradient chain).
 FUSED_MLP = os.environ.get("UNETK_SWIN_FUSED_MLP", "1") != "0"
 FUSED_MLP_SAVE_ACT = os.environ.get("UNETK_SWIN_MLP_SAVE_ACT", "1") != "0"
+# ... and its data-gradient chain (fc2's data gradient, GELU', fc1's data gradient, LayerNorm backward) as one launch
+FUSED_MLP_BWD = os.environ.get("UNETK_SWIN_FUSED_MLP_BWD", "1") != "0"
 _SIDE_STREAMS = {}
 
 
@@ -450,18 +461,30 @@ def _block_bwd(blk, pre, ctx, dx2, cx, grads, db2=None, keep_next=None):
         db = db2
     else:
         db = ops.scale_sample(dx2, keep2) if keep2 is not None else dx2
-    # d hidden = (d out @ W2) * GELU'(pre-activation): inside the GEMM's epilogue where the hidden tensor is
-    # large (it saves one write and one read of it); on the small late stages the separate pass is as fast
-    if hpre.numel() >= _FUSE_GELU_BWD_ELEMS:
-        dhp = _linear_bwd(hact, db, blk.mlp[3].weight, cx, grads, pre + "mlp.3.weight", pre + "mlp.3.bias",
-                          gelu_grad_of=hpre, x_from=hpre)
+    p64t = cx.packed64(blk.mlp[3].weight, "bn64_t") if (FUSED_MLP_BWD and cx.sums is not None and not padded) else None
+    if p64t is not None and ops.swin_mlp_supported(x1) and db.is_contiguous():
+        # the whole data-gradient chain of the branch in one launch; the two weight gradients read db and its dhp
+        w1, w2 = blk.mlp[0].weight, blk.mlp[3].weight
+        dhp, dx1, grads[pre + "norm2.weight"], grads[pre + "norm2.bias"], dxs = ops.swin_mlp_bwd(
+            db, hpre, p64t, cx.packed(w1, transpose=True), x1, m2, r2, blk.norm2.weight, dx2, cx.sums,
+            scale_next=(keep1, H * W) if keep1 is not None else None)
+        _linear_bwd(hact, db, w2, cx, grads, pre + "mlp.3.weight", pre + "mlp.3.bias", need_dx=False, x_from=hpre)
+        _linear_bwd(ln2, dhp, w1, cx, grads, pre + "mlp.0.weight", pre + "mlp.0.bias", need_dx=False)
+        res = (dx1, None, None, dxs)
     else:
-        dh = _linear_bwd(hact, db, blk.mlp[3].weight, cx, grads, pre + "mlp.3.weight", pre + "mlp.3.bias", x_from=hpre)
-        dhp = ops.gelu_bwd(dh, hpre)
-    dln2 = _linear_bwd(ln2, dhp, blk.mlp[0].weight, cx, grads, pre + "mlp.0.weight", pre + "mlp.0.bias")
-    res = ops.layernorm_bwd(dln2, x1, blk.norm2.weight, m2, r2, add=dx2, defer=cx.sums,
-                            scale_next=(keep1, H * W) if (fuse and keep1 is not None) else None)
-    dx1, grads[pre + "norm2.weight"], grads[pre + "norm2.bias"] = res[:3]
+        # d hidden = (d out @ W2) * GELU'(pre-activation): inside the GEMM's epilogue where the hidden tensor is
+        # large (it saves one write and one read of it); on the small late stages the separate pass is as fast
+        if hpre.numel() >= _FUSE_GELU_BWD_ELEMS:
+            dhp = _linear_bwd(hact, db, blk.mlp[3].weight, cx, grads, pre + "mlp.3.weight", pre + "mlp.3.bias",
+                              gelu_grad_of=hpre, x_from=hpre)
+        else:
+            dh = _linear_bwd(hact, db, blk.mlp[3].weight, cx, grads, pre + "mlp.3.weight", pre + "mlp.3.bias",
+                             x_from=hpre)
+            dhp = ops.gelu_bwd(dh, hpre)
+        dln2 = _linear_bwd(ln2, dhp, blk.mlp[0].weight, cx, grads, pre + "mlp.0.weight", pre + "mlp.0.bias")
+        res = ops.layernorm_bwd(dln2, x1, blk.norm2.weight, m2, r2, add=dx2, defer=cx.sums,
+                                scale_next=(keep1, H * W) if (fuse and keep1 is not None) else None)
+        dx1, grads[pre + "norm2.weight"], grads[pre + "norm2.bias"] = res[:3]
     # attention branch
     if len(res) == 4 and res[3] is not None:
         db = res[3]
