@@ -465,6 +465,19 @@ def run_swin(args, rank, world, dev, dt):
             "roofline": roof, "cpu_baseline": cpu}
     if reducer is not None:
         reducer.detach()
+    if rec is not None and world == 1 and not graphed and not args.no_small_batch:
+        # the data-parallel form of the same step on this one GPU: gradients copied into the reducer's flat
+        # buckets from both streams of the backward pass, each bucket's collective replaced by a no-op
+        from unet_amd.dist import GradReducer
+        reducer = GradReducer(model, collective=lambda flat: None, force=True)
+        for _ in range(3):
+            eager_step()
+        el_dp = timed(eager_step, args.steps, 0, world, dev)
+        rec["dp_path"] = {"ms_per_step": round(el_dp / args.steps * 1e3, 3), "buckets": len(reducer.buckets),
+                          "what": "the same step with the data-parallel gradient sink installed (bucket fills on both "
+                                  "streams of the backward pass, deferred sums in their own bucket; no-op collective)"}
+        reducer.detach()
+        reducer = None
     del model, opt, crit, x, y, w
     torch.cuda.empty_cache()
     if rec is not None and world == 1 and args.graph == "auto" and B > GRAPH_MAX_BATCH and not args.no_small_batch:

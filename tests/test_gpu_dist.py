@@ -140,7 +140,9 @@ def test_two_rank_step_equals_mean_of_per_shard_gradients():
             per_shard.append({n: p.grad.detach().cpu().double() for n, p in model.named_parameters()})
         for r in range(world):
             grads, params, launched, nbuckets = gathered[r][name]
-            assert launched >= nbuckets - 1, (name, launched, nbuckets)
+            # every bucket but the last (and, for the Swin model, the bucket of the sums taken at the end) left
+            # from inside the backward pass
+            assert launched >= nbuckets - 2, (name, launched, nbuckets)
             for n in per_shard[0]:
                 want = ((per_shard[0][n] + per_shard[1][n]) / world).numpy()
                 head, total, norm, _ = grads[n]
@@ -148,6 +150,15 @@ def test_two_rank_step_equals_mean_of_per_shard_gradients():
                 assert float(np.abs(head - want.reshape(-1)[:32]).max()) <= 1e-5 * scale + 1e-9, (name, r, n)
                 assert abs(norm - float(np.linalg.norm(want))) <= 1e-5 * float(np.linalg.norm(want)) + 1e-9, (name, r, n)
                 assert abs(total - float(want.sum())) <= 1e-4 * float(np.abs(want).sum()) + 1e-9, (name, r, n)
+        # ... and bit for bit: the sum of two fp32 tensors and the halving are exact operations on bits that the
+        # deterministic kernels reproduce, so the reduced gradient equals the one formed here from the sink-less
+        # per-shard runs (the Swin backward fills the buckets from two streams and hands the LayerNorm / bias-table
+        # sums over after its closing launch: a bucket sent too early would show here)
+        import hashlib
+        for n in per_shard[0]:
+            a, b = per_shard[0][n].float(), per_shard[1][n].float()
+            want_hash = hashlib.sha1(((a + b) * 0.5).numpy().tobytes()).hexdigest()
+            assert gathered[0][name][0][n][3] == want_hash, (name, n)
         for n in gathered[0][name][1]:
             assert gathered[0][name][1][n] == gathered[1][name][1][n], (name, n)   # replicas stay in step, bit for bit
         for n in gathered[0][name][0]:

@@ -20,14 +20,49 @@ class GradOut(dict):
     data-parallel reducer's ``grad_sink(name, tensor) -> tensor``) every gradient is handed over the
     moment its kernel is queued, so its bucket's all-reduce can start while the backward continues."""
 
-    def __init__(self, sink=None):
+    def __init__(self, sink=None, late=()):
+        """late: names whose tensors are complete only once the backward's closing launches have run (sums taken at
+        its end): they are handed to the sink by flush_late(), not when they are assigned."""
         super().__init__()
         self.sink = sink
+        self.late = frozenset(late) if sink is not None else frozenset()
+        self._held = []
 
     def __setitem__(self, name, grad):
         if self.sink is not None and grad is not None:
-            grad = self.sink(name, grad)
+            if name in self.late:
+                self._held.append(name)
+            else:
+                # a gradient computed on another stream (see on_stream) is handed over on that stream: the sink's
+                # copy into its bucket is then ordered behind the kernel that produces the gradient
+                st = getattr(grad, "_unetk_stream", None)
+                if st is not None:
+                    with torch.cuda.stream(st):
+                        grad = self.sink(name, grad)
+                else:
+                    grad = self.sink(name, grad)
         dict.__setitem__(self, name, grad)
+
+    def flush_late(self):
+        for name in self._held:
+            dict.__setitem__(self, name, self.sink(name, dict.__getitem__(self, name)))
+        self._held = []
+
+
+def on_stream(t, st):
+    """Marks tensor t as produced on HIP stream st (read by GradOut); returns t."""
+    if t is not None and st is not None:
+        t._unetk_stream = st
+    return t
+
+
+def view_as_param(t, shape):
+    """t.view(shape) that keeps the stream mark."""
+    v = t.view(shape)
+    st = getattr(t, "_unetk_stream", None)
+    if st is not None:
+        v._unetk_stream = st
+    return v
 
 
 def _vec(dt):

@@ -166,6 +166,15 @@ class SwinUNet(nn.Module):
             if m.bias is not None:
                 nn.init.constant_(m.bias, 0)
 
+    def late_grad_names(self):
+        """Parameters whose gradients the backward pass completes with its closing launches (the LayerNorm weight /
+        bias sums and the relative-position table sums of every block, taken together at the end): a data-parallel
+        reducer keeps them in a bucket of their own."""
+        if not DEFER_LN_SUMS:
+            return []
+        return [n for n, _ in _named_params(self)
+                if n.endswith("relative_position_bias_table") or ".norm" in n or n.startswith("norm_embed.")]
+
     def _draw_drop_path(self, B, device):
         if self.drop_path_override is not None:
             return [[None if k is None else k.to(device=device, dtype=torch.float32).contiguous() for k in pair]
@@ -312,8 +321,8 @@ class _Ctx:
 # Weight gradients are off the critical chain of the backward pass (data gradient -> norm backward ->
 # data gradient ...).  The Swin encoder's late stages launch many small kernels (512-768 workgroups, one
 # round of the chip or less): run on a second HIP stream, their weight gradients fill the CUs the
-# chain leaves idle at every kernel's ramp-up and tail.  Off with a data-parallel gradient sink
-# (the sink copies each gradient on the main stream as soon as it is produced).
+# chain leaves idle at every kernel's ramp-up and tail.  A data-parallel gradient sink receives each of those
+# gradients on that second stream (unet_amd.dist.GradReducer orders its buckets' collectives behind both streams).
 OVERLAP_WGRAD = os.environ.get("UNETK_SWIN_OVERLAP_WGRAD", "1") != "0"
 DEFER_LN_SUMS = os.environ.get("UNETK_SWIN_DEFER_LN_SUMS", "1") != "0"     # LayerNorm dgamma / dbeta sums: one launch at the end of the backward
 CONVT_BWD_GATHER = os.environ.get("UNETK_SWIN_CONVT_BWD_GATHER", "1") != "0"   # ConvTranspose data gradient reads the gradient image in place
@@ -354,6 +363,7 @@ def _on_side(cx, fn, *operands):
     for t in (res if isinstance(res, tuple) else (res,)):
         if t is not None:
             t.record_stream(main)
+            ops.on_stream(t, cx.side)
     return res
 
 
@@ -388,7 +398,7 @@ def _linear_bwd(x, dy, w, cx, grads, wname, bname, need_dx=True, gelu_grad_of=No
         dw, db = _on_side(cx, lambda: ops.linear_wgrad(x, dy, Ci, Co, want_bias=bname is not None), x, dy)
     if bname is not None:
         grads[bname] = db
-    grads[wname] = dw.view(w.shape)
+    grads[wname] = ops.view_as_param(dw, w.shape)
     if need_dx:
         return _linear_launch(dy, cx.packed(w.view(Co, Ci), transpose=True), gelu_grad_of=gelu_grad_of)
     return None
@@ -593,8 +603,8 @@ def _decoder_head_bwd(dec, pre, ctx, dcat, cx, grads):
         dsp = dcat[..., up:]
         if resized is not None:
             dsp = ops.upsample_bwd(dsp.contiguous(), up, resized[0], resized[1])
-        grads[pre + "skip_projection.weight"] = _on_side(
-            cx, lambda: ops.linear_wgrad(skip, dsp, wsk.shape[1], up, want_bias=False)[0], skip, dsp).view(wsk.shape)
+        grads[pre + "skip_projection.weight"] = ops.view_as_param(_on_side(
+            cx, lambda: ops.linear_wgrad(skip, dsp, wsk.shape[1], up, want_bias=False)[0], skip, dsp), wsk.shape)
         dskip = _linear_launch(dsp, cx.packed(wsk, transpose=True))
     return dx, dskip
 
@@ -664,14 +674,14 @@ class _SwinTrainFn(torch.autograd.Function):
             raise RuntimeError("the SwinUNet step was already back-propagated: its saved activations are freed "
                                "by the first backward (run the forward again)")
         cx = save[0][1]                 # dtype and the packs made by this step's forward
-        grads = ops.GradOut(model.grad_sink)
         main = torch.cuda.current_stream()
-        cx.side = _side_stream(dout.device) if (OVERLAP_WGRAD and model.grad_sink is None) else None
-        # dgamma / dbeta of the 25 LayerNorms: their partial tables are summed by one launch at the end (a gradient
-        # sink wants every gradient complete the moment it is handed over: then each sum runs in place)
+        cx.side = _side_stream(dout.device) if OVERLAP_WGRAD else None
+        # dgamma / dbeta of the 25 LayerNorms: their partial tables are summed by one launch at the end
         # (not while a HIP graph is being captured: the job table would be uploaded from host memory inside the graph)
-        cx.sums = ops.DeferredSums() if (DEFER_LN_SUMS and model.grad_sink is None and
-                                         not torch.cuda.is_current_stream_capturing()) else None
+        cx.sums = ops.DeferredSums() if (DEFER_LN_SUMS and not torch.cuda.is_current_stream_capturing()) else None
+        # a gradient sink (data-parallel buckets) gets every gradient on the stream that produced it, and the ones
+        # the closing launch completes after that launch
+        grads = ops.GradOut(model.grad_sink, model.late_grad_names() if cx.sums is not None else ())
         nl = model.num_layers
         dskips: Dict[int, torch.Tensor] = {}
         g = None
@@ -731,6 +741,7 @@ class _SwinTrainFn(torch.autograd.Function):
         if cx.sums is not None:
             cx.sums.flush()
             cx.sums = None
+        grads.flush_late()
         if cx.side is not None:
             main.wait_stream(cx.side)
             cx.side = None
