@@ -19,7 +19,16 @@ import torch.nn as nn
 from . import ops
 
 _WS = 8
-_FUSE_GELU_BWD_ELEMS = 1 << 25
+# GELU' inside the epilogue of fc2's data gradient: on the wide token grids it saves a write and a read of the hidden
+# gradient, on the deep stages a launch (measured per layer at batch 64: 55 against 36 + 32 us at 16x16 tokens)
+_FUSE_GELU_BWD_ELEMS = int(os.environ.get("UNETK_SWIN_GELU_BWD_ELEMS", "0"))
+FUSE_GELU_FWD = os.environ.get("UNETK_SWIN_FUSE_GELU_FWD", "1") != "0"
+_GELU_FWD_MAX_TOKENS = 1 << 15
+
+
+def hidden_small(x, blk):
+    """Whether the block's token grid is one of the deep ones, where fc1 writes GELU as a second output."""
+    return x.numel() // x.shape[-1] <= _GELU_FWD_MAX_TOKENS
 
 
 # ------------------------------------------------------------------ parameter containers
@@ -446,9 +455,14 @@ def _block_fwd(blk, pre, x, keep1, keep2, cx, save):
                                                         want_act=FUSED_MLP_SAVE_ACT or save is None)
     else:
         ln2, m2, r2 = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
-        # (GELU stays its own pass: fc1 writing both tensors is bound by the same two writes, measured equal or slower)
-        hpre = _linear(ln2, blk.mlp[0].weight, blk.mlp[0].bias, cx)
-        hact = ops.gelu_fwd(hpre)
+        if FUSE_GELU_FWD and hidden_small(x1, blk):
+            # the deep stages (few tokens, wide layers): GELU as a second output of fc1's epilogue saves a launch
+            # in a part of the step where launches, not bytes, set the time
+            hpre, hact = _linear(ln2, blk.mlp[0].weight, blk.mlp[0].bias, cx, act=2, out2=True)
+        else:
+            # (on the wide token grids fc1 writing both tensors is bound by the same two writes: measured equal or slower)
+            hpre = _linear(ln2, blk.mlp[0].weight, blk.mlp[0].bias, cx)
+            hact = ops.gelu_fwd(hpre)
         x2 = _linear(hact, blk.mlp[3].weight, blk.mlp[3].bias, cx, resid=x1, keep=keep2)
     if save is not None:
         save.append(("block", blk, pre, (x, m1, r1, ln1p, qkv, att, x1, m2, r2, ln2, hpre, hact, keep1, keep2,
