@@ -19,4 +19,5 @@ for w in train swin predict; do
       $G/${w}_mfma/vm/*_counter_collection.csv ${P}_${w}_pmc_roofline.csv \
       "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE), bench.py --workload $w"
 done
-python tools/pmc_traffic.py $G/train_fetch/vm/*_counter_collection.csv $G/train_write/vm/*_counter_collection.csv $D/pmc_traffic.json
+python tools/pmc_traffic.py $G/train_fetch/vm/*_counter_collection.csv $G/train_write/vm/*_counter_collection.csv $D/pmc_traffic.json $G/train_mfma/vm/*_counter_collection.csv
+python tools/pmc_traffic.py $G/swin_fetch/vm/*_counter_collection.csv $G/swin_write/vm/*_counter_collection.csv $D/pmc_traffic_swin.json $G/swin_mfma/vm/*_counter_collection.csv

@@ -1,7 +1,10 @@
 #!/usr/bin/env python
 """HBM traffic per launch from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE, separate runs).
 
-    python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>
+    python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [<mfma counter_collection.csv>]
+
+With the fourth file (a pass of SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE) every kernel also gets
+"mfma_util" = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs), as tools/roofline_table.py.
 
 Both counters are in KiB.  On gfx950 FETCH_SIZE tallies the 128-byte requests of wide coalesced
 reads at 64 bytes, so the read side is doubled; WRITE_SIZE is exact for 16-byte-per-lane stores.
@@ -47,6 +50,15 @@ for base, ks in fam.items():
             out[base + "+plain"] = out[base]
         out[base] = {"launches_sampled": n, "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
                      "hbm_bytes_per_launch": round(rd + wr), "variants": sorted(k for k in ks if k != base) + [base + "+plain"]}
+if len(sys.argv) > 4:
+    busy, _ = per_kernel(sys.argv[4], "SQ_VALU_MFMA_BUSY_CYCLES")
+    act, _ = per_kernel(sys.argv[4], "GRBM_GUI_ACTIVE")
+    for k in out:
+        base = k.split("+")[0]
+        ks = [k] if k in act else [x for x in act if x.split("+")[0] == base]
+        a = sum(act[x] for x in ks)
+        if a > 0:
+            out[k]["mfma_util"] = round(sum(busy[x] for x in ks) / (a / 8.0 * 1024.0), 4)
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 for k, v in list(out.items())[:12]:
     print(k, v)
