@@ -202,6 +202,15 @@ int unetk_bn_act_bwd_rank1(const float* gpix, const float* gchan, const void* y,
                            const float* scale, const float* shift, const float* mean, const float* invstd,
                            const float* keep, int relu, float* dgamma, float* dbeta, int accumulate,
                            float* partials, float* sums, int dtype, unetk_stream_t stream);
+/* Same with the gradient that comes back through a 2x2 max-pool AND a skip connection (the last activation of an
+ * encoder block, training.py:497-503, 524-531 in the backward): g = dskip + route(dpooled by argmax), i.e. what
+ * unetk_pool_bwd would store (same rounding), formed inside both passes instead of written once and read twice.
+ * dskip has row stride ldskip; argmax is the map unetk_bn_act_fwd left. */
+int unetk_bn_act_bwd_pool(const void* dpooled, const unsigned char* argmax, const void* dskip, int ldskip,
+                          const void* y, void* dy, int B, int H, int W, int C, const float* scale, const float* shift,
+                          const float* mean, const float* invstd, const float* keep, int relu, float* dgamma,
+                          float* dbeta, int accumulate, float* partials, float* sums, int dtype,
+                          unetk_stream_t stream);
 /* da = dskip + route(dpooled to the first maximum of each 2x2 quad): the maximum is taken from
  * argmax when given (a may then be null), else recomputed from a. */
 int unetk_pool_bwd(const void* a, const unsigned char* argmax, const void* dpooled, const void* dskip,

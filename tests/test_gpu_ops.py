@@ -225,6 +225,30 @@ def test_pool_bwd_first_max_and_skip(dt, shape):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 16, 16, 16), (3, 9, 7, 48), (2, 2, 2, 8), (1, 32, 30, 96), (2, 5, 4, 768),
+                                   (3, 70, 50, 48)])
+def test_bn_bwd_with_the_pool_gradient_formed_inside(dt, shape):
+    """BatchNorm backward whose incoming gradient is pool_bwd(dpooled, dskip, argmax) formed inside both passes
+    (unetk_bn_act_bwd_pool): the same bits as the stored tensor gives, odd sizes and a strided skip gradient
+    included."""
+    from unet_amd import ops
+    B, H, W, C = shape
+    y = nhwc((rnd((B, C, H, W), 40, dt) * 1.5 + 0.3), dt)
+    stats = torch.stack([y.float().sum((0, 1, 2)), (y.float() ** 2).sum((0, 1, 2))]).view(1, 2, C).contiguous()
+    gamma, beta = (torch.rand(C) + 0.5).cuda(), (torch.randn(C) * 0.2).cuda()
+    mean, invstd, sc, sh = ops.bn_finalize(stats, B * H * W, gamma, beta, None, None)
+    keep = ((torch.rand(B, C) > 0.3).float() / 0.7).cuda()
+    a, pooled, amap = ops.bn_act_fwd(y, sc, sh, keep, relu=True, pool=True, want_argmax=True)
+    gp = nhwc(rnd((B, C, H // 2, W // 2), 41, dt), dt)
+    wide = nhwc(rnd((B, C + 8, H, W), 42, dt), dt)
+    for dskip in (wide[..., 8:], wide[..., 8:].contiguous()):
+        g = ops.pool_bwd(None, gp, dskip, argmax=amap)
+        dy0, dg0, db0 = ops.bn_act_bwd(g, y, sc, sh, mean, invstd, keep, relu=True)
+        dy1, dg1, db1 = ops.bn_act_bwd(ops.PooledGrad(gp, dskip, amap), y, sc, sh, mean, invstd, keep, relu=True)
+        assert torch.equal(dy0, dy1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("hw", [((8, 8), (16, 16)), ((6, 9), (12, 18)), ((12, 18), (25, 36)), ((1, 1), (3, 3)),
                                 ((3, 5), (7, 11)), ((1, 1), (2, 2)), ((2, 3), (4, 6)), ((1, 5), (2, 10)),
                                 ((5, 1), (10, 2)), ((17, 9), (34, 18))])

@@ -76,6 +76,7 @@ _SIGNATURES = {
     "unetk_reduce_num_partials": (I, [L]),
     "unetk_bn_act_bwd": (I, [P, P, P, I, I, I, I, P, P, P, P, P, I, P, P, I, P, P, I, P]),
     "unetk_bn_act_bwd_rank1": (I, [P, P, P, P, I, I, I, I, P, P, P, P, P, I, P, P, I, P, P, I, P]),
+    "unetk_bn_act_bwd_pool": (I, [P, P, P, I, P, P, I, I, I, I, P, P, P, P, P, I, P, P, I, P, P, I, P]),
     "unetk_pool_bwd": (I, [P, P, P, P, I, P, I, I, I, I, I, P]),
     "unetk_upsample_concat_fwd": (I, [P, I, I, I, P, I, I, P, I, I, I, I, P]),
     "unetk_upsample_bwd": (I, [P, I, I, I, P, I, I, I, I, I, P]),

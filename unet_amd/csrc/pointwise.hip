@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
         Vec16<T> o;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-          float z = to_f32(v[k].v[e]) * sc[e] + sh[e];
+          float z = fmaf(to_f32(v[k].v[e]), sc[e], sh[e]);
           if (relu) z = fmaxf(z, 0.f);
           z *= kp[e];
           o.v[e] = from_f32<T>(z);
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void bn_act_stream_kernel(const T* __restrict_
     Vec16<T> o;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      float z = to_f32(v.v[e]) * sc[e] + sh[e];
+      float z = fmaf(to_f32(v.v[e]), sc[e], sh[e]);
       if (relu) z = fmaxf(z, 0.f);
       o.v[e] = from_f32<T>(z * kp[e]);
     }
@@ -304,8 +304,42 @@ struct RedArgs {
   float* partials;      // [nblk][2][C]
   const float* g1_d;    // MODE 0, rank-one gradient: g[p][c] = round_T(g1_d[p] * g1_w[c]) instead of reading g
   const float* g1_w;
+  const void* dpooled;  // MODE 0, gradient through a 2x2 max-pool formed on the fly: g[p][c] = round_T(g[p][c] +
+  const unsigned char* argmax;   // (argmax[quad][c] == place of p in its quad ? dpooled[quad][c] : 0)), see PoolSrc
+  int H, W;
   long npix, hw;
   int C, ldx, ldg, chunk, relu;
+};
+
+// Gradient of the input of a 2x2 max-pool whose input also feeds a skip connection, for one pixel and one channel
+// group, as pool_bwd_kernel would have stored it: the skip gradient plus the pooled gradient of the pixel's quad
+// where the forward's argmax map names this pixel, rounded to T.  The BatchNorm-backward passes read it through
+// this loader instead of a stored tensor (a tensor written once and read twice otherwise).
+template <typename T>
+struct PoolSrc {
+  static constexpr int E = Vec16<T>::N;
+  const T* dskip;
+  const T* dpooled;
+  const unsigned char* argmax;
+  int ldskip, H, W, C, c0;
+  __device__ __forceinline__ Vec16<T> at(unsigned p, unsigned b, unsigned hw) const {
+    const unsigned rem = p - b * hw;
+    const unsigned yy = rem / (unsigned)W, xx = rem - yy * (unsigned)W;
+    Vec16<T> sk = load16(dskip + (size_t)p * ldskip + c0);
+    if ((int)(yy | 1) < H && (int)(xx | 1) < W) {
+      const size_t q = (((size_t)b * (H >> 1) + (yy >> 1)) * (W >> 1) + (xx >> 1)) * C + c0;
+      const unsigned k = ((yy & 1) << 1) | (xx & 1);
+      const Vec16<T> d = load16(dpooled + q);
+#pragma unroll
+      for (int e = 0; e < E; e += 4) {
+        const unsigned packed = *reinterpret_cast<const unsigned*>(argmax + q + e);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (((packed >> (8 * i)) & 255u) == k) sk.v[e + i] = from_f32<T>(to_f32(sk.v[e + i]) + to_f32(d.v[e + i]));
+      }
+    }
+    return sk;
+  }
 };
 
 template <typename T, int MODE>
@@ -352,13 +386,25 @@ __global__ __launch_bounds__(RED_THREADS) void channel_reduce_kernel(RedArgs a) 
           for (int e = 0; e < E; ++e) {
             const float yv = to_f32(xv.v[e]);
             float dz = to_f32(gv.v[e]) * kp[e];
-            if (a.relu && !(yv * sc[e] + sh[e] > 0.f)) dz = 0.f;
+            // (explicit fused multiply-adds: every instantiation of this loop, and the forward's own
+            //  y*scale+shift, must round alike, whatever the compiler would contract in each)
+            if (a.relu && !(fmaf(yv, sc[e], sh[e]) > 0.f)) dz = 0.f;
             s0[e] += dz;
-            s1[e] += dz * ((yv - mu[e]) * is[e]);
+            s1[e] = fmaf(dz, (yv - mu[e]) * is[e], s1[e]);
           }
         };
         long p = seg + pl;
-        if (a.g1_d != nullptr) {
+        if (a.dpooled != nullptr) {
+          const PoolSrc<T> src{gp, reinterpret_cast<const T*>(a.dpooled), a.argmax, a.ldg, a.H, a.W, a.C, c0};
+          const unsigned hw = (unsigned)a.hw, bb = (unsigned)b;
+          for (; p + lanes < seg_end; p += 2 * lanes) {
+            const Vec16<T> x0 = load16(x + p * a.ldx + c0), x1 = load16(x + (p + lanes) * a.ldx + c0);
+            const Vec16<T> g0 = src.at((unsigned)p, bb, hw), g1 = src.at((unsigned)(p + lanes), bb, hw);
+            one(x0, g0);
+            one(x1, g1);
+          }
+          if (p < seg_end) one(load16(x + p * a.ldx + c0), src.at((unsigned)p, bb, hw));
+        } else if (a.g1_d != nullptr) {
           // the gradient of the last activation is an outer product (per-pixel scalar x per-channel
           // weight of the final 1x1 conv): formed here, rounded as the stored tensor would be
           float wv[E];
@@ -535,13 +581,15 @@ template <typename T>
 __global__ __launch_bounds__(RED_THREADS) void bn_act_bwd_apply_kernel(
     const T* __restrict__ g, const T* __restrict__ y, T* __restrict__ dy, unsigned npix, unsigned hw, int C,
     const float* __restrict__ coef, const float* __restrict__ keep, int relu, unsigned chunk,
-    const float* __restrict__ g1_d, const float* __restrict__ g1_w) {
+    const float* __restrict__ g1_d, const float* __restrict__ g1_w, const T* __restrict__ dpooled,
+    const unsigned char* __restrict__ argmax, int ldg, int H, int W) {
   constexpr int E = Vec16<T>::N;
   const int CG = C / E;
   const int lanes = RED_THREADS / CG;
   const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
   if (pl >= lanes) return;
   const int c0 = cg * E;
+  const PoolSrc<T> src{g, dpooled, argmax, ldg, H, W, C, c0};
   float sc[E], sh[E], k1[E], k0[E];
   load_params<E>(coef + c0, sc);
   load_params<E>(coef + C + c0, sh);
@@ -553,7 +601,8 @@ __global__ __launch_bounds__(RED_THREADS) void bn_act_bwd_apply_kernel(
   float wv[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) wv[e] = g1_d != nullptr ? g1_w[c0 + e] : 0.f;
-  auto gload = [&](unsigned p) {
+  auto gload = [&](unsigned p, unsigned b) {
+    if (dpooled != nullptr) return src.at(p, b, hw);      // (uniform) gradient through the max-pool formed on the fly
     if (g1_d != nullptr) {      // (uniform) rank-one gradient formed on the fly
       const float d = g1_d[p];
       Vec16<T> gv;
@@ -569,8 +618,8 @@ __global__ __launch_bounds__(RED_THREADS) void bn_act_bwd_apply_kernel(
     for (int e = 0; e < E; ++e) {
       const float yy = to_f32(yv.v[e]);
       float dz = to_f32(gv.v[e]) * kp[e];
-      if (relu && !(yy * sc[e] + sh[e] > 0.f)) dz = 0.f;
-      o.v[e] = from_f32<T>(sc[e] * dz + k1[e] * yy + k0[e]);
+      if (relu && !(fmaf(yy, sc[e], sh[e]) > 0.f)) dz = 0.f;
+      o.v[e] = from_f32<T>(fmaf(sc[e], dz, fmaf(k1[e], yy, k0[e])));
     }
     store16(dy + (size_t)p * C + c0, o);
   };
@@ -589,12 +638,12 @@ __global__ __launch_bounds__(RED_THREADS) void bn_act_bwd_apply_kernel(
     }
     unsigned p = seg + pl;
     for (; p + lanes < seg_end; p += 2 * lanes) {     // two pixels (four loads) in flight
-      const Vec16<T> g0 = gload(p), y0 = load16(y + (size_t)p * C + c0);
-      const Vec16<T> g1 = gload(p + lanes), y1 = load16(y + (size_t)(p + lanes) * C + c0);
+      const Vec16<T> g0 = gload(p, b), y0 = load16(y + (size_t)p * C + c0);
+      const Vec16<T> g1 = gload(p + lanes, b), y1 = load16(y + (size_t)(p + lanes) * C + c0);
       one(p, g0, y0, kp);
       one(p + lanes, g1, y1, kp);
     }
-    if (p < seg_end) one(p, gload(p), load16(y + (size_t)p * C + c0), kp);
+    if (p < seg_end) one(p, gload(p, b), load16(y + (size_t)p * C + c0), kp);
     seg = seg_end;
   }
 }
@@ -1223,7 +1272,8 @@ int unetk_reduce_num_partials(int64_t npix) { return reduce_blocks(npix); }
 static int bn_act_bwd_impl(const void* g, const float* g1_d, const float* g1_w, const void* y, void* dy, int B, int H,
                            int W, int C, const float* scale, const float* shift, const float* mean,
                            const float* invstd, const float* keep, int relu, float* dgamma, float* dbeta,
-                           int accumulate, float* partials, float* sums, int dtype, hipStream_t stream) {
+                           int accumulate, float* partials, float* sums, int dtype, hipStream_t stream,
+                           const void* dpooled = nullptr, const unsigned char* argmax = nullptr, int ldg = 0) {
   UNETK_CHECK_ARG((g || (g1_d && g1_w)) && y && dy && scale && shift && mean && invstd && partials && sums,
                   "bn_act_bwd: null pointer");
   CHECK_DTYPE("bn_act_bwd", dtype);
@@ -1235,8 +1285,9 @@ static int bn_act_bwd_impl(const void* g, const float* g1_d, const float* g1_w, 
   const int nblk = reduce_blocks(npix);
   RedArgs r;
   r.x = y; r.g = g; r.scale = scale; r.shift = shift; r.mean = mean; r.invstd = invstd; r.keep = keep;
-  r.partials = partials; r.npix = npix; r.hw = (long)H * W; r.C = C; r.ldx = C; r.ldg = C;
+  r.partials = partials; r.npix = npix; r.hw = (long)H * W; r.C = C; r.ldx = C; r.ldg = dpooled ? ldg : C;
   r.chunk = cdiv(npix, nblk); r.relu = relu; r.g1_d = g1_d; r.g1_w = g1_w;
+  r.dpooled = dpooled; r.argmax = argmax; r.H = H; r.W = W;
   DISPATCH_T(dtype, hipLaunchKernelGGL((channel_reduce_kernel<T, 0>), dim3(nblk), dim3(RED_THREADS), 0,
                                        stream, r));
   UNETK_CHECK_LAUNCH();
@@ -1255,7 +1306,7 @@ static int bn_act_bwd_impl(const void* g, const float* g1_d, const float* g1_w, 
     DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_bwd_apply_kernel<T>, dim3((unsigned)cdiv(npix, chunk)),
                                          dim3(RED_THREADS), 0, stream, (const T*)g, (const T*)y, (T*)dy,
                                          (unsigned)npix, (unsigned)((long)H * W), C, coef, keep, relu, chunk,
-                                         g1_d, g1_w));
+                                         g1_d, g1_w, (const T*)dpooled, argmax, dpooled ? ldg : C, H, W));
   }
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
@@ -1277,6 +1328,18 @@ int unetk_bn_act_bwd_rank1(const float* gpix, const float* gchan, const void* y,
   UNETK_CHECK_ARG(gpix && gchan, "bn_act_bwd_rank1: null gradient factors");
   return bn_act_bwd_impl(nullptr, gpix, gchan, y, dy, B, H, W, C, scale, shift, mean, invstd, keep, relu, dgamma,
                          dbeta, accumulate, partials, sums, dtype, stream);
+}
+
+int unetk_bn_act_bwd_pool(const void* dpooled, const unsigned char* argmax, const void* dskip, int ldskip,
+                          const void* y, void* dy, int B, int H, int W, int C, const float* scale, const float* shift,
+                          const float* mean, const float* invstd, const float* keep, int relu, float* dgamma,
+                          float* dbeta, int accumulate, float* partials, float* sums, int dtype, hipStream_t stream) {
+  UNETK_CHECK_ARG(dpooled && argmax && dskip, "bn_act_bwd_pool: null gradient, argmax map or skip gradient");
+  UNETK_CHECK_ARG(H >= 2 && W >= 2, "bn_act_bwd_pool: image smaller than one quad");
+  const int E = dtype == UNETK_BF16 ? 8 : 4;
+  UNETK_CHECK_ARG(ldskip >= C && ldskip % E == 0, "bn_act_bwd_pool: skip stride %d", ldskip);
+  return bn_act_bwd_impl(dskip, nullptr, nullptr, y, dy, B, H, W, C, scale, shift, mean, invstd, keep, relu, dgamma,
+                         dbeta, accumulate, partials, sums, dtype, stream, dpooled, argmax, ldskip);
 }
 
 int unetk_pool_bwd(const void* a, const unsigned char* argmax, const void* dpooled, const void* dskip,

@@ -463,10 +463,19 @@ def maxpool2x2(a):
     return bn_act_fwd(a, None, None, None, relu=False, pool=True, write_a=False)[1]
 
 
+class PooledGrad:
+    """Stands for pool_bwd(None, dpooled, dskip, argmax) without storing it (see bn_act_bwd)."""
+    __slots__ = ("dpooled", "dskip", "argmax")
+
+    def __init__(self, dpooled, dskip, argmax):
+        self.dpooled, self.dskip, self.argmax = dpooled, dskip, argmax
+
+
 def bn_act_bwd(g, y, scale, shift, mean, invstd, keep=None, relu=True, dgamma=None, dbeta=None,
                accumulate=False):
     """Returns (dy, dgamma, dbeta).  ``g`` is the gradient of the activation, or a pair (gpix (B,H,W) fp32,
-    gchan (C,) fp32) standing for the rank-one gradient gpix[b,y,x] * gchan[c] that is never materialised."""
+    gchan (C,) fp32) standing for the rank-one gradient gpix[b,y,x] * gchan[c] that is never materialised, or a
+    PooledGrad: the gradient through a 2x2 max-pool plus a skip gradient, formed inside the passes."""
     B, H, W, C = y.shape
     dev = y.device
     dy = torch.empty_like(y)
@@ -477,6 +486,13 @@ def bn_act_bwd(g, y, scale, shift, mean, invstd, keep=None, relu=True, dgamma=No
         dgamma = torch.empty(C, dtype=torch.float32, device=dev)
         dbeta = torch.empty(C, dtype=torch.float32, device=dev)
         accumulate = False
+    if isinstance(g, PooledGrad):
+        assert g.dpooled.shape == (B, H // 2, W // 2, C) and g.dskip.shape == (B, H, W, C) and g.dskip.stride(3) == 1
+        assert g.dpooled.is_contiguous() and g.argmax.is_contiguous() and g.dskip.stride(1) == W * g.dskip.stride(2)
+        call("unetk_bn_act_bwd_pool", ptr(g.dpooled), ptr(g.argmax), ptr(g.dskip), g.dskip.stride(2), ptr(y), ptr(dy),
+             B, H, W, C, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(keep), 1 if relu else 0, ptr(dgamma),
+             ptr(dbeta), 1 if accumulate else 0, ptr(partials), ptr(sums), dtype_code(y.dtype), stream())
+        return dy, dgamma, dbeta
     if isinstance(g, tuple):
         gpix, gchan = g
         if gchan.numel() < C:       # channel padding of the activation: the padded channels get no gradient

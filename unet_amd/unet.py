@@ -103,6 +103,9 @@ class OptimizedUNet(nn.Module):
 # Weight gradients on a second HIP stream: measured neutral on MI355X once both kernel families ran
 # near their own limits (they compete for the same CUs), so it is off unless asked for.
 OVERLAP_WGRAD = os.environ.get("UNETK_OVERLAP_WGRAD", "0") != "0"
+# the gradient through an encoder's max-pool (+ its skip gradient) formed inside the BatchNorm-backward passes
+# instead of stored by a pass of its own (0: the separate pass, for A/B timing; same bits either way)
+FUSE_POOL_BWD = os.environ.get("UNETK_FUSE_POOL_BWD", "1") != "0"
 _SIDE_STREAMS = {}
 
 
@@ -371,7 +374,10 @@ class _UNetTrainFn(torch.autograd.Function):
             g = ops.upsample_bwd(g_up, C1, lh, lw)
         g = block_bwd("bottleneck", g)
         for enc in reversed(enc_names):
-            g = ops.pool_bwd(None, g, dskips[enc], argmax=saved[enc][1])
+            if FUSE_POOL_BWD and dskips[enc].shape[1] >= 2 and dskips[enc].shape[2] >= 2:
+                g = ops.PooledGrad(g, dskips[enc], saved[enc][1])      # formed inside the BatchNorm-backward passes
+            else:
+                g = ops.pool_bwd(None, g, dskips[enc], argmax=saved[enc][1])
             g = block_bwd(enc, g, need_dx=(enc != "encoder1") or ctx.need_dx)
         dx = None
         if ctx.need_dx:
