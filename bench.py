@@ -116,10 +116,20 @@ def launch_ranks(n, argv):
 
 
 # ---------------------------------------------------------------------------- timing helpers
+# UNETK_BENCH_FORCE_DIST=1: take every multi-rank branch with a ONE-rank RCCL group (process group on "nccl",
+# GradReducer with its default asynchronous all-reduce, barriers, rank maxima, the predictor's band exchange): the
+# rehearsal of the --gpus N path that a box with one GPU can run.
+FORCE_DIST = os.environ.get("UNETK_BENCH_FORCE_DIST") == "1"
+
+
+def multi(world):
+    return world > 1 or FORCE_DIST
+
+
 def barrier_sync(world, gpu=True):
     if gpu:
         torch.cuda.synchronize()
-    if world > 1:
+    if multi(world):
         import torch.distributed as dist
         dist.barrier()
         if gpu:
@@ -145,7 +155,7 @@ def settle(fn, world, dev, max_seconds, batch=10):
         dt_ = time.perf_counter() - t0
         n += batch
         stop = time.perf_counter() - t_begin > max_seconds
-        if world > 1:
+        if multi(world):
             import torch.distributed as dist
             v = torch.tensor([dt_, float(stop)], dtype=torch.float64, device=dev)
             dist.all_reduce(v, op=dist.ReduceOp.MAX)
@@ -166,7 +176,7 @@ def timed(fn, steps, warmup, world, dev):
         fn()
     barrier_sync(world)
     el = time.perf_counter() - t0
-    if world > 1:
+    if multi(world):
         import torch.distributed as dist
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -288,11 +298,11 @@ def run_train(args, rank, world, dev, dt):
     x, y, w = W.synthetic_batch(args.batch, 4, args.size, args.size, seed=42 + rank)
     x, y, w = x.to(dev), y.to(dev), w.to(dev)
     reducer = None
-    if world > 1:
+    if multi(world):
         from unet_amd.dist import GradReducer
-        reducer = GradReducer(model)
+        reducer = GradReducer(model, force=FORCE_DIST)
     # the trainer's optimizer tail (enhanced_training_multi_loss.py:758-763, 827-829)
-    graphed = args.graph == "on" and world == 1
+    graphed = args.graph == "on" and not multi(world)
     opt = FusedAdamW(model.parameters(), lr=5e-5, weight_decay=5e-5, max_grad_norm=1.0, capturable=graphed)
 
     def step():
@@ -392,15 +402,15 @@ def run_swin(args, rank, world, dev, dt):
     x, y, w = x.to(dev), y.to(dev), w.to(dev)
     crit = MultiLossFunction(SWIN_LOSS_CFG).to(dev)
     reducer = None
-    if world > 1:
+    if multi(world):
         from unet_amd.dist import GradReducer
-        reducer = GradReducer(model)
+        reducer = GradReducer(model, force=FORCE_DIST)
     # Small batches on one rank: the whole step is captured into a HIP graph and replayed (the ~600 launches of
     # a step cost the host ~13 ms, more than the GPU needs below ~32 patches; measured 6.3 ms graphed vs 14.4 ms
     # eager at the reference's batch of 6, but 16.2 vs 15.7 ms at batch 64, where the GPU is the limit and the
     # graph's per-node dispatch costs more than eager launches that run ahead).  Several ranks: eager, the bucket
     # all-reduces start from inside the backward pass.
-    graphed = args.graph == "on" or (args.graph == "auto" and world == 1 and B <= GRAPH_MAX_BATCH)
+    graphed = args.graph == "on" or (args.graph == "auto" and not multi(world) and B <= GRAPH_MAX_BATCH)
     opt = FusedAdamW(model.parameters(), lr=1e-4, weight_decay=0.05, max_grad_norm=1.0, capturable=graphed)
 
     def resize(out, labels):
@@ -465,7 +475,7 @@ def run_swin(args, rank, world, dev, dt):
             "roofline": roof, "cpu_baseline": cpu}
     if reducer is not None:
         reducer.detach()
-    if rec is not None and world == 1 and not graphed and not args.no_small_batch:
+    if rec is not None and not multi(world) and not graphed and not args.no_small_batch:
         # the data-parallel form of the same step on this one GPU: gradients copied into the reducer's flat
         # buckets from both streams of the backward pass, each bucket's collective replaced by a no-op
         from unet_amd.dist import GradReducer
@@ -480,7 +490,7 @@ def run_swin(args, rank, world, dev, dt):
         reducer = None
     del model, opt, crit, x, y, w
     torch.cuda.empty_cache()
-    if rec is not None and world == 1 and args.graph == "auto" and B > GRAPH_MAX_BATCH and not args.no_small_batch:
+    if rec is not None and not multi(world) and args.graph == "auto" and B > GRAPH_MAX_BATCH and not args.no_small_batch:
         # the reference trainer's own batch size (swin_unet_model.py:728), where the step is launch-bound
         import copy
         small = copy.copy(args)
@@ -821,8 +831,12 @@ def main():
         return
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if multi(world):
         import torch.distributed as dist
+        if world == 1 and "MASTER_ADDR" not in os.environ:       # the one-rank rehearsal started by hand
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), RANK="0", WORLD_SIZE="1")
+        # (a box may export NCCL_DEBUG=VERSION: RCCL's banner then goes to stderr, stdout carries the one JSON line)
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
         dist.init_process_group("nccl", device_id=dev)
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     runners = {"train": run_train, "swin": run_swin, "predict": run_predict}
@@ -836,13 +850,13 @@ def main():
                 extra[name] = runners[name](args, rank, world, dev, dt)
             except Exception as e:      # the headline line must still come out; the failure is recorded in it
                 extra[name] = {"error": f"{type(e).__name__}: {e}"}
-                if world > 1:
+                if multi(world):
                     raise
         if rank == 0:
             line.update(extra)
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi(world):
         dist.barrier()
         dist.destroy_process_group()
 

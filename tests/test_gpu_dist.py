@@ -163,3 +163,47 @@ def test_two_rank_step_equals_mean_of_per_shard_gradients():
             assert gathered[0][name][1][n] == gathered[1][name][1][n], (name, n)   # replicas stay in step, bit for bit
         for n in gathered[0][name][0]:
             assert gathered[0][name][0][n][3] == gathered[1][name][0][n][3], (name, n)   # same reduced gradient on both
+
+
+def test_one_rank_rccl_group_runs_the_default_collective():
+    """The reducer's DEFAULT collective - an asynchronous dist.all_reduce on the "nccl" (= RCCL) backend, issued from
+    inside the backward pass on whatever stream filled the bucket - with a one-rank group on the one GPU of the box:
+    every call a multi-GPU step makes into RCCL is made, and the sum over one rank must hand back the sink-less
+    gradients bit for bit, for both models and two steps in a row."""
+    import socket
+    import torch.distributed as dist
+    from unet_amd.dist import GradReducer
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        for name, model in _models().items():
+            want = []
+            for _ in range(2):
+                for p in model.parameters():
+                    p.grad = None
+                _step(model, name, 0)
+                torch.cuda.synchronize()
+                want.append({n: p.grad.detach().clone() for n, p in model.named_parameters()})
+            red = GradReducer(model, bucket_bytes=(256 << 10) if name == "unet" else (8 << 20), force=True)
+            assert model.grad_sink is not None and len(red.buckets) > 1
+            for k in range(2):
+                for p in model.parameters():
+                    p.grad = None
+                _step(model, name, 0)
+                launched = sum(b.work is not None for b in red.buckets)
+                red.finish()
+                torch.cuda.synchronize()
+                assert launched >= len(red.buckets) - 2, (name, launched, len(red.buckets))
+                for n, p in model.named_parameters():
+                    assert torch.equal(p.grad, want[k][n]), (name, k, n)
+            red.detach()
+            t = torch.ones(4, device="cuda")
+            dist.all_reduce(t)
+            dist.barrier()
+            assert t.sum().item() == 4.0
+    finally:
+        dist.destroy_process_group()
