@@ -76,8 +76,8 @@ __device__ __forceinline__ void wait_vm_barrier_g(int n) {
 #undef UNETK_WVB
 }
 
-template <int TM, int TN>
-__global__ __launch_bounds__(256) void lin_gemm_kernel(GemmArgs a) {
+template <int TM, int TN, bool GIN = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void lin_gemm_kernel(GemmArgs a) {
   static_assert(TN % 2 == 0, "channel tiles are taken in pairs");
   constexpr int BM = 64 * TM, BN = 16 * TN;
   constexpr int APIECES = BM / 16, WPIECES = BN / 16;          // 1 KiB DMA pieces per chunk
@@ -100,51 +100,55 @@ __global__ __launch_bounds__(256) void lin_gemm_kernel(GemmArgs a) {
   // ---- DMA sources.  Token piece i: rows 16i .. 16i+15, lane -> (row 16i + lane/4, 16-byte slot
   // (lane&3) ^ swz(row)); rows past M read zeros.  Weight piece j: row 16j + lane/4 of the block,
   // slot (lane&3) ^ 2*(j&1) (the swizzle that keeps the permuted fragment reads conflict-free).
-  constexpr int APW = (APIECES + 3) / 4, WPW = (WPIECES + 3) / 4;
+  // Every wave issues the same number of pieces per chunk (a wave whose index falls past the last piece
+  // sends one of the existing pieces again: same bytes to the same place), so "all but the newest chunk"
+  // is one compile-time vmcnt and the steady-state loop has no branch but its own.
+  constexpr int APW = (APIECES + 3) / 4, WPW = (WPIECES + 3) / 4, NP = APW + WPW;
+  static_assert(2 * NP <= 16, "counted waits");
   const bf16* zero = reinterpret_cast<const bf16*>(gemm_zero_page);
   const bf16* asrc[APW];
+  int astep[APW], adst[APW];
 #pragma unroll
   for (int k = 0; k < APW; ++k) {
-    const int i = wave + 4 * k;
+    int i = wave + 4 * k;
+    if (i >= APIECES) i -= 4;
     const int row = 16 * i + (lane >> 2);
     const int slot = (lane & 3) ^ swz(row);
     long first = (long)(m0 + row) * a.ldx;          // element offset of the token's row
-    if (a.gin_up) {                                  // ... or of pixel (b, 2y, 2x) of the gradient image
+    if constexpr (GIN) {                             // ... or of pixel (b, 2y, 2x) of the gradient image
       const int t = m0 + row, bb = t / a.gin_hw, rem = t - bb * a.gin_hw, y = rem / a.gin_w, x = rem - y * a.gin_w;
       first = (((long)bb * 4 * a.gin_hw) + (long)(2 * y) * (2 * a.gin_w) + 2 * x) * a.ldx;
     }
-    asrc[k] = (i < APIECES && m0 + row < a.M) ? a.x + first + slot * 8 : nullptr;
+    const bool ok = m0 + row < a.M;
+    asrc[k] = ok ? a.x + first + slot * 8 : zero;
+    astep[k] = ok ? 1 : 0;                           // rows past M stay on the page of zeros
+    adst[k] = i * 1024;
   }
   // element offset of chunk ch inside the token's row (plain: ch * 32)
-  const int gin_cpq = a.gin_up ? a.gin_up / 32 : 1;
+  const int gin_cpq = GIN ? a.gin_up / 32 : 1;
   auto chunk_off = [&](int ch) -> long {
-    if (!a.gin_up) return (long)ch * 32;
+    if constexpr (!GIN) return (long)ch * 32;
     const int qd = ch / gin_cpq, c0 = (ch - qd * gin_cpq) * 32;
     return ((long)(qd >> 1) * (2 * a.gin_w) + (qd & 1)) * a.ldx + c0;
   };
   const bf16* wbase = a.w + (long)nb * a.nchunks * BN * 32;
-  int woff[WPW];
+  int woff[WPW], wdst[WPW];
 #pragma unroll
   for (int k = 0; k < WPW; ++k) {
-    const int j = wave + 4 * k;
+    int j = wave + 4 * k;
+    while (j >= WPIECES) j -= (WPIECES >= 4 ? 4 : WPIECES);
     woff[k] = (16 * j + (lane >> 2)) * 32 + (((lane & 3) ^ (2 * (j & 1))) * 8);
+    wdst[k] = BM * 64 + j * 1024;
   }
-  auto issue = [&](int ch) {
-    char* dst = lds + (ch % NSTAGE) * STAGE;
+  auto issue = [&](int ch, int stage) __attribute__((always_inline)) {
+    char* dst = lds + stage * STAGE;
     const long coff = chunk_off(ch);
 #pragma unroll
-    for (int k = 0; k < APW; ++k) {
-      const int i = wave + 4 * k;
-      if (i < APIECES) glds16g(asrc[k] != nullptr ? asrc[k] + coff : zero, dst + i * 1024);
-    }
+    for (int k = 0; k < APW; ++k) glds16g(asrc[k] + coff * astep[k], dst + adst[k]);
     const bf16* ws = wbase + (long)ch * BN * 32;
 #pragma unroll
-    for (int k = 0; k < WPW; ++k) {
-      const int j = wave + 4 * k;
-      if (j < WPIECES) glds16g(ws + woff[k], dst + BM * 64 + j * 1024);
-    }
+    for (int k = 0; k < WPW; ++k) glds16g(ws + woff[k], dst + wdst[k]);
   };
-  const int my_pieces = (APIECES - wave + 3) / 4 + (WPIECES - wave + 3) / 4;
 
   // ---- fragment addresses (see the header comment for the weight row order)
   const int l15 = lane & 15, q = lane >> 4;
@@ -155,27 +159,93 @@ __global__ __launch_bounds__(256) void lin_gemm_kernel(GemmArgs a) {
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TN; ++j) {
+      acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // (opaque to the optimiser and held in vector registers: left alone, the accumulators went to accumulation
+      // registers that the allocator rotated through the two halves of the unrolled loop, ~70 copies per 24 MFMAs)
+      asm volatile("" : "+v"(acc[i][j]));
+    }
 
-  issue(0);
-  if (a.nchunks > 1) issue(1);
-#pragma unroll 1
-  for (int ch = 0; ch < a.nchunks; ++ch) {
-    // this chunk's pieces (issued two chunks ago) have landed; the next chunk's stay in flight
-    wait_vm_barrier_g(ch + 1 < a.nchunks ? my_pieces : 0);
-    if (ch + 2 < a.nchunks) issue(ch + 2);
-    const char* st = lds + (ch % NSTAGE) * STAGE;
-    bf16x8 xf[TM], wf[TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(st + a_lane + i * 16 * 64);
+  // The fragments are double-buffered in registers: while chunk ch is multiplied out of one set, the ds_reads of
+  // chunk ch+1 fill the other, one read between MFMAs, so a wave's LDS round trip and its MFMAs overlap.  The
+  // barrier that opens iteration ch therefore waits for chunk ch+1; by then every wave has the fragments of chunk
+  // ch in registers, so stage ch % 3 is free for chunk ch+3: two chunks stay in flight behind the one being read.
+  // A chunk is only 12 MFMAs per wave, so what surrounds them counts: the steady-state iteration below is
+  // straight-line code (no modulo, no division, no run-time wait count); only the last four chunks take branches.
+  bf16x8 xf[2][TM], wf[2][TN];
+  auto load_frags = [&](auto bufc, int stage) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(bufc)::value;
+    const char* st = lds + stage * STAGE;
 #pragma unroll
     for (int j = 0; j < TN; ++j)
-      wf[j] = *reinterpret_cast<const bf16x8*>(st + w_lane + (32 * (j >> 1) + 4 * (j & 1)) * 64);
+      wf[BUF][j] = *reinterpret_cast<const bf16x8*>(st + w_lane + (32 * (j >> 1) + 4 * (j & 1)) * 64);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) xf[BUF][i] = *reinterpret_cast<const bf16x8*>(st + a_lane + i * 16 * 64);
+  };
+  auto multiply = [&](auto curc) __attribute__((always_inline)) {
+    constexpr int CUR = decltype(curc)::value;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[CUR][j], xf[CUR][i], acc[i][j], 0, 0, 0);
+  };
+  auto interleave = [&]() __attribute__((always_inline)) {      // issue order: a ds_read behind every MFMA until the reads are out
+    constexpr int NRD = TM + TN, NMM = TM * TN, MPR = NMM / NRD > 0 ? NMM / NRD : 1;
+#pragma unroll
+    for (int k = 0; k < NRD; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    if constexpr (NMM - MPR * NRD > 0) __builtin_amdgcn_sched_group_barrier(0x008, NMM - MPR * NRD, 0);
+  };
+  auto next3 = [](int st) { return st == 2 ? 0 : st + 1; };
+  int sr = 1, si = 0;          // stage of chunk ch+1 (read next), stage of chunk ch+3 (= that of chunk ch: refilled next)
+  auto steady = [&](auto curc, int ch) __attribute__((always_inline)) {      // chunks ch+1, ch+2, ch+3 all exist
+    constexpr int CUR = decltype(curc)::value;
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NP) : "memory");
+    issue(ch + 3, si);
+    load_frags(std::integral_constant<int, CUR ^ 1>{}, sr);
+    multiply(curc);
+    interleave();
+    sr = next3(sr);
+    si = next3(si);
+  };
+  auto tail = [&](auto curc, int ch) __attribute__((always_inline)) {        // one of the last three chunks
+    constexpr int CUR = decltype(curc)::value;
+    if (ch + 1 < a.nchunks) {          // (uniform)
+      if (ch + 2 < a.nchunks) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NP) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      load_frags(std::integral_constant<int, CUR ^ 1>{}, sr);
+    }
+    multiply(curc);
+    sr = next3(sr);
+  };
+  issue(0, 0);
+  if (a.nchunks > 1) issue(1, 1);
+  if (a.nchunks > 2) issue(2, 2);
+  if (a.nchunks > 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NP) : "memory");      // chunk 0 has landed
+  else if (a.nchunks > 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NP) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  load_frags(std::integral_constant<int, 0>{}, 0);
+  {
+    // steady-state pairs while chunk ch+4 exists, then the last three or four chunks
+    int ch = 0;
+#pragma unroll 1
+    for (; ch + 4 < a.nchunks; ch += 2) {
+      steady(std::integral_constant<int, 0>{}, ch);
+      steady(std::integral_constant<int, 1>{}, ch + 1);
+    }
+    if (ch + 3 < a.nchunks) {
+      steady(std::integral_constant<int, 0>{}, ch);
+      tail(std::integral_constant<int, 1>{}, ch + 1);
+      tail(std::integral_constant<int, 0>{}, ch + 2);
+      tail(std::integral_constant<int, 1>{}, ch + 3);
+    } else {
+      if (ch < a.nchunks) tail(std::integral_constant<int, 0>{}, ch);
+      if (ch + 1 < a.nchunks) tail(std::integral_constant<int, 1>{}, ch + 1);
+      if (ch + 2 < a.nchunks) tail(std::integral_constant<int, 0>{}, ch + 2);
+    }
   }
 
   // ---- epilogue: lane (q, token l15) holds channels n0 + 32p + 8q .. +7 of its token for pair p
@@ -812,12 +882,12 @@ int launch_rows(const void* x, const void* dy, float* dw, float* db, long M, voi
 
 #define UNETK_ROWS_SHAPES(X) X(96, 288) X(96, 96) X(96, 384) X(384, 96) X(192, 576) X(192, 192) X(192, 768) X(768, 192)
 
-template <int TM, int TN> int launch_gemm(GemmArgs a, hipStream_t stream) {
+template <int TM, int TN, bool GIN = false> int launch_gemm(GemmArgs a, hipStream_t stream) {
   constexpr int BM = 64 * TM;
   a.mtiles = cdiv(a.M, BM);
   a.tiles_per_xcd = cdiv(a.mtiles, 8);
   a.nby = a.N / (16 * TN);
-  hipLaunchKernelGGL((lin_gemm_kernel<TM, TN>), dim3((unsigned)(8 * a.tiles_per_xcd * a.nby)), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL((lin_gemm_kernel<TM, TN, GIN>), dim3((unsigned)(8 * a.tiles_per_xcd * a.nby)), dim3(256), 0, stream, a);
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }
@@ -932,9 +1002,9 @@ int unetk_convt2x2_bwd_data(const void* dout, int lddo, const void* wpackedT, vo
   a.shuf_up = a.shuf_w = a.shuf_hw = 0;
   a.gin_up = up; a.gin_w = w; a.gin_hw = h * w;
   switch (bn) {
-    case 96: return launch_gemm<2, 6>(a, stream);
-    case 64: return launch_gemm<2, 4>(a, stream);
-    default: return launch_gemm<2, 2>(a, stream);
+    case 96: return launch_gemm<2, 6, true>(a, stream);
+    case 64: return launch_gemm<2, 4, true>(a, stream);
+    default: return launch_gemm<2, 2, true>(a, stream);
   }
 }
 
