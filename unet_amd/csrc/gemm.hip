@@ -399,23 +399,56 @@ __global__ __launch_bounds__(64 * WM * WN) void lin_wgrad_kernel(WgArgs a) {
     x_tok[k] = (i < XPIECES && c < a.K) ? t : (1 << 20);
     x_off[k] = t * a.ldx + c;
   }
-  auto issue = [&](int st) {
-    char* dst = lds + (st % NSTAGE) * STAGE;
+  static_assert(DPIECES % NW == 0 && XPIECES % NW == 0 && NSTAGE == 3, "every wave issues the same pieces; ring of three");
+  constexpr int NP = DPW + XPW;
+  static_assert(2 * NP <= 16, "counted waits");
+  // Full stages (all 32 tokens inside the range) are fetched through running pointers: one 64-bit add per piece and
+  // no bounds test; only a last, partial stage takes the checked form.
+  const int nfull = t_begin < t_end ? (t_end - t_begin) / TT : 0;
+  const bf16* dptr[DPW];
+  const bf16* xptr[XPW];
+  long dstep[DPW], xstep[XPW];
+#pragma unroll
+  for (int k = 0; k < DPW; ++k) {
+    const bool ok = d_tok[k] < (1 << 20);
+    dptr[k] = ok ? a.dy + (long)t_begin * a.lddy + d_off[k] : zero;
+    dstep[k] = ok ? (long)TT * a.lddy : 0;
+  }
+#pragma unroll
+  for (int k = 0; k < XPW; ++k) {
+    const bool ok = x_tok[k] < (1 << 20);
+    xptr[k] = ok ? a.x + (long)t_begin * a.ldx + x_off[k] : zero;
+    xstep[k] = ok ? (long)TT * a.ldx : 0;
+  }
+  auto issue_full = [&](int slot) __attribute__((always_inline)) {
+    char* dst = lds + slot * STAGE;
+#pragma unroll
+    for (int k = 0; k < DPW; ++k) {
+      glds16g(dptr[k], dst + (wave + NW * k) * 1024);
+      dptr[k] += dstep[k];
+    }
+#pragma unroll
+    for (int k = 0; k < XPW; ++k) {
+      glds16g(xptr[k], dst + DBYTES + (wave + NW * k) * 1024);
+      xptr[k] += xstep[k];
+    }
+  };
+  auto issue_any = [&](int st, int slot) __attribute__((always_inline)) {
+    if (st < nfull) {          // (uniform)
+      issue_full(slot);
+      return;
+    }
+    char* dst = lds + slot * STAGE;
     const int t0 = t_begin + st * TT;
     const bf16* dbase = a.dy + (long)t0 * a.lddy;
     const bf16* xbase = a.x + (long)t0 * a.ldx;
 #pragma unroll
-    for (int k = 0; k < DPW; ++k) {
-      const int i = wave + NW * k;
-      if (i < DPIECES) glds16g(t0 + d_tok[k] < t_end ? dbase + d_off[k] : zero, dst + i * 1024);
-    }
+    for (int k = 0; k < DPW; ++k)
+      glds16g(t0 + d_tok[k] < t_end ? dbase + d_off[k] : zero, dst + (wave + NW * k) * 1024);
 #pragma unroll
-    for (int k = 0; k < XPW; ++k) {
-      const int i = wave + NW * k;
-      if (i < XPIECES) glds16g(t0 + x_tok[k] < t_end ? xbase + x_off[k] : zero, dst + DBYTES + i * 1024);
-    }
+    for (int k = 0; k < XPW; ++k)
+      glds16g(t0 + x_tok[k] < t_end ? xbase + x_off[k] : zero, dst + DBYTES + (wave + NW * k) * 1024);
   };
-  const int my_pieces = (DPIECES - wave + NW - 1) / NW + (XPIECES - wave + NW - 1) / NW;
 
   // ---- transposing-read addresses: group g = lane/16 reads tokens 8g+4h+q (h = 0, 1), lane (q, p) of the
   // group supplies channels 4p..4p+3 of the 16-channel tile
@@ -434,46 +467,102 @@ __global__ __launch_bounds__(64 * WM * WN) void lin_wgrad_kernel(WgArgs a) {
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     accb[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("" : "+v"(accb[m]));
 #pragma unroll
-    for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < 4; ++n) {
+      acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      asm volatile("" : "+v"(acc[m][n]));      // (held in vector registers, opaque to the optimiser: see lin_gemm_kernel)
+    }
   }
   const bool want_bias = a.bias_slab != nullptr && wn == 0 && k0 == 0;
 
-#pragma unroll
-  for (int k = 0; k < AHEAD; ++k)
-    if (k < nstage) issue(k);
-#pragma unroll 1
-  for (int st = 0; st < nstage; ++st) {
-    // this stage's pieces have landed once at most the pieces of the younger stages in flight remain
-    const int younger = nstage - 1 - st < AHEAD - 1 ? nstage - 1 - st : AHEAD - 1;
-    wait_vm_barrier_g(younger * my_pieces);
-    if (st + AHEAD < nstage) issue(st + AHEAD);
-    const char* base = lds + (st % NSTAGE) * STAGE;
-    bf16x8 af[4], bfr[4];
+  // As in lin_gemm_kernel: the fragments of stage st+1 are read (transposing reads, one between MFMAs) while stage
+  // st is multiplied out of the other register set; the barrier that opens iteration st waits for stage st+1, and
+  // slot st % 3, whose fragments every wave already holds, takes stage st+3.  The steady-state iteration is
+  // straight-line code with a compile-time wait count; the last stages of a range take the general form.
+  typedef __attribute__((ext_vector_type(8))) short short8v;
+  bf16x8 af[2][4], bfr[2][4];
+  auto load_frags = [&](auto bufc, int slot) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(bufc)::value;
+    const char* base = lds + slot * STAGE;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, base + a_addr[m]));
       const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, base + a_addr[m] + 4 * RBD));
-      typedef __attribute__((ext_vector_type(8))) short short8v;
-      af[m] = __builtin_bit_cast(bf16x8, short8v{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+      af[BUF][m] = __builtin_bit_cast(bf16x8, short8v{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
     }
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
       const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, base + b_addr[n]));
       const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, base + b_addr[n] + 4 * RBX));
-      typedef __attribute__((ext_vector_type(8))) short short8v;
-      bfr[n] = __builtin_bit_cast(bf16x8, short8v{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+      bfr[BUF][n] = __builtin_bit_cast(bf16x8, short8v{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
     }
+  };
+  auto multiply = [&](auto curc) __attribute__((always_inline)) {
+    constexpr int CUR = decltype(curc)::value;
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
       for (int n = 0; n < 4; ++n)
-        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[CUR][m], bfr[CUR][n], acc[m][n], 0, 0, 0);
+  };
+  auto bias_mma = [&](auto curc) __attribute__((always_inline)) {
+    constexpr int CUR = decltype(curc)::value;
     if (want_bias) {      // (wave-uniform) dy^T times a matrix of ones: every column = the sum over the stage's tokens
       const u32x4 ones = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
 #pragma unroll
       for (int m = 0; m < 4; ++m)
-        accb[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], __builtin_bit_cast(bf16x8, ones), accb[m], 0, 0, 0);
+        accb[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[CUR][m], __builtin_bit_cast(bf16x8, ones), accb[m], 0, 0, 0);
+    }
+  };
+  auto next3 = [](int st) { return st == 2 ? 0 : st + 1; };
+  int sr = 1, si = 0;          // slot of stage st+1 (read next), slot of stage st+3 (= that of stage st)
+  auto steady = [&](auto curc) __attribute__((always_inline)) {      // stages st+1, st+2 exist and st+3 is a full stage
+    constexpr int CUR = decltype(curc)::value;
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NP) : "memory");
+    issue_full(si);
+    load_frags(std::integral_constant<int, CUR ^ 1>{}, sr);
+    multiply(curc);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {          // issue order: a transposing read behind every MFMA
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    bias_mma(curc);
+    sr = next3(sr);
+    si = next3(si);
+  };
+  auto general = [&](auto curc, int st) __attribute__((always_inline)) {
+    constexpr int CUR = decltype(curc)::value;
+    if (st + 1 < nstage) {          // (uniform)
+      if (st + 2 < nstage) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NP) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (st + 3 < nstage) issue_any(st + 3, si);
+      load_frags(std::integral_constant<int, CUR ^ 1>{}, sr);
+    }
+    multiply(curc);
+    bias_mma(curc);
+    sr = next3(sr);
+    si = next3(si);
+  };
+  if (nstage > 0) {
+    issue_any(0, 0);
+    if (nstage > 1) issue_any(1, 1);
+    if (nstage > 2) issue_any(2, 2);
+    if (nstage > 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NP) : "memory");      // stage 0 has landed
+    else if (nstage > 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    load_frags(std::integral_constant<int, 0>{}, 0);
+    int st = 0;
+#pragma unroll 1
+    for (; st + 4 < nfull; st += 2) {
+      steady(std::integral_constant<int, 0>{});
+      steady(std::integral_constant<int, 1>{});
+    }
+#pragma unroll 1
+    for (; st < nstage; st += 2) {
+      general(std::integral_constant<int, 0>{}, st);
+      if (st + 1 < nstage) general(std::integral_constant<int, 1>{}, st + 1);
     }
   }
 
