@@ -305,8 +305,10 @@ def run_train(args, rank, world, dev, dt):
     graphed = args.graph == "on" and not multi(world)
     opt = FusedAdamW(model.parameters(), lr=5e-5, weight_decay=5e-5, max_grad_norm=1.0, capturable=graphed)
 
+    params = list(model.parameters())        # (zero_grad as the optimizer does it: over its own list, no module walk)
+
     def step():
-        for p in model.parameters():
+        for p in params:
             p.grad = None
         loss, _ = crit(model(x), y, w)
         loss.backward()
@@ -416,8 +418,10 @@ def run_swin(args, rank, world, dev, dt):
     def resize(out, labels):
         return ops.interpolate_bilinear(out, labels.shape[-2:]) if out.shape[-2:] != labels.shape[-2:] else out
 
+    params = list(model.parameters())        # (zero_grad as the optimizer does it: over its own list, no module walk)
+
     def eager_step():
-        for p in model.parameters():
+        for p in params:
             p.grad = None
         loss, _ = crit(resize(model(x), y), y, w)
         loss.backward()

@@ -34,6 +34,11 @@ enum { UNETK_ACT_NONE = 0, UNETK_ACT_RELU = 1, UNETK_ACT_GELU = 2 };
 
 const char* unetk_last_error(void);
 int unetk_version(void);
+/* Stream `to` waits for everything queued so far on stream `from` (both on the current device): hipEventRecord +
+ * hipStreamWaitEvent on an event from a ring the library keeps per device.  No counterpart in the reference (it has no
+ * second stream); the weight-gradient stream of the backward passes is forked with it at ~2 us per call, where the
+ * framework's event objects cost the host ~15 us. */
+int unetk_stream_fork(unetk_stream_t from, unetk_stream_t to);
 
 /* ---- convolution as implicit GEMM on MFMA ------------------------------------------
  * nn.Conv2d(k=3, padding=1) / nn.Conv2d(k=1) / nn.Linear:

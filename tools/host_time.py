@@ -57,10 +57,26 @@ if os.environ.get("HOST_PROFILE"):
     import cProfile, pstats
     torch.cuda.synchronize()
     pr = cProfile.Profile()
+    # the backward pass runs in the autograd engine's thread: it gets a profiler of its own
+    from unet_amd import swin as swin_mod
+    pr2 = cProfile.Profile()
+    orig_bwd = swin_mod._SwinTrainFn.backward
+
+    def prof_bwd(ctx, dout):
+        pr2.enable()
+        try:
+            return orig_bwd(ctx, dout)
+        finally:
+            pr2.disable()
+    swin_mod._SwinTrainFn.backward = staticmethod(prof_bwd)
     pr.enable()
     for _ in range(5):
         step()
     pr.disable()
+    swin_mod._SwinTrainFn.backward = staticmethod(orig_bwd)
+    print("---- backward thread")
+    pstats.Stats(pr2).sort_stats(os.environ.get("HOST_PROFILE_SORT", "tottime")).print_stats(40)
+    print("---- calling thread")
     torch.cuda.synchronize()
     st = pstats.Stats(pr)
-    st.sort_stats("tottime").print_stats(28)
+    st.sort_stats(os.environ.get("HOST_PROFILE_SORT", "tottime")).print_stats(45)

@@ -31,6 +31,7 @@ P, I, L, F, D = c_void_p, c_int, c_int64, c_float, c_double
 _SIGNATURES = {
     "unetk_last_error": (c_char_p, []),
     "unetk_version": (I, []),
+    "unetk_stream_fork": (I, [P, P]),
     "unetk_conv_pick_bn": (I, [I]),
     "unetk_conv_packed_elems": (L, [I, I, I, I, I]),
     "unetk_conv_pack_weight": (I, [P, P, I, I, I, I, I, I, P]),

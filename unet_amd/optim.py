@@ -111,6 +111,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self.last_grad_norm = None
         self.capturable = capturable
         self._lists = {}
+        self._fast = {}         # group index -> what step() keeps between calls (see there)
         self._hyper = {}        # group index -> (hyper double[5] on the device, dyn float[3], last pushed (lr, wd, betas))
 
     # ------------------------------------------------------------------ device-resident step / lr (capturable)
@@ -160,6 +161,7 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
+        self._fast.clear()
         for gi, group in enumerate(self.param_groups):
             b1, b2 = group["betas"]
             for p in group["params"]:
@@ -246,24 +248,38 @@ class FusedAdamW(torch.optim.Optimizer):
             params = [p for p in group["params"] if p.grad is not None]
             if not params:
                 continue
-            for p in params:
-                st = self.state[p]
-                if not st:
-                    st["step"] = torch.zeros((), dtype=torch.float32)
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            steps = {int(self.state[p]["step"]) for p in params}
-            if len(steps) != 1:
-                raise RuntimeError("parameters of one group must share their step count")
-            step = steps.pop() + 1
-            for p in params:
-                self.state[p]["step"] += 1
-            tl = self._list_for(gi, params)
-            grads = _grads_of(params)
+            fast = self._fast.get(gi)
+            if fast is not None and fast[0] == len(params) and fast[1] is params[0] and fast[2] is params[-1] and \
+                    self.state[params[-1]].get("step") is fast[3] and \
+                    fast[8] == (params[0].data_ptr(), params[-1].data_ptr()):
+                # the same parameters as last step (the usual case): ONE step counter shared by the group's states,
+                # the address tables of parameters and moments kept (they never move)
+                _, _, _, step_t, tl, pp, mp, vp, _ = fast
+                step = int(step_t) + 1
+                step_t += 1
+            else:
+                for p in params:
+                    st = self.state[p]
+                    if not st:
+                        st["step"] = torch.zeros((), dtype=torch.float32)
+                        st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                        st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                steps = {int(self.state[p]["step"]) for p in params}
+                if len(steps) != 1:
+                    raise RuntimeError("parameters of one group must share their step count")
+                step = steps.pop() + 1
+                step_t = self.state[params[0]]["step"]
+                step_t += 1
+                for p in params[1:]:         # one counter object for the whole group from now on
+                    self.state[p]["step"] = step_t
+                tl = self._list_for(gi, params)
+                pp = tl.pointers(params, "p")
+                mp = tl.pointers([self.state[p]["exp_avg"] for p in params], "m")
+                vp = tl.pointers([self.state[p]["exp_avg_sq"] for p in params], "v")
+                self._fast[gi] = (len(params), params[0], params[-1], step_t, tl, pp, mp, vp,
+                                  (params[0].data_ptr(), params[-1].data_ptr()))
             b1, b2 = group["betas"]
-            pp, gp = tl.pointers(params, "p"), tl.pointers(grads, "g")
-            mp = tl.pointers([self.state[p]["exp_avg"] for p in params], "m")
-            vp = tl.pointers([self.state[p]["exp_avg_sq"] for p in params], "v")
+            gp = tl.pointers(_grads_of(params), "g")
             if self.capturable:
                 # (the host-side counters above only count the calls made outside graph replays; the device
                 # counter is the truth: device_step_count())

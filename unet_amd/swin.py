@@ -16,7 +16,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _lib, ops
 
 _WS = 8
 # GELU' inside the epilogue of fc2's data gradient: on the wide token grids it saves a write and a read of the hidden
@@ -242,11 +242,12 @@ class _Ctx:
     for training the data-gradient form) and looked up by the parameter's address; anything not
     found there (a reshaped copy) is packed on the spot.  Owned by the autograd node of the step
     (or dropped after an inference call): interleaved models or steps cannot see each other's packs."""
-    __slots__ = ("dt", "pool", "side", "held", "tracked", "sums")
+    __slots__ = ("dt", "pool", "side", "fork", "held", "tracked", "sums")
 
     def __init__(self, model, training):
         self.dt = dt = model.compute_dtype
         self.side = None        # set by the backward pass: the stream the weight gradients run on
+        self.fork = None
         self.held = []
         self.tracked = []       # BatchNorm step counters of this forward: advanced by one launch at its end
         self.sums = None        # set by the backward pass: the LayerNorm parameter-gradient sums taken at its end
@@ -257,28 +258,36 @@ class _Ctx:
             cand = model.__dict__["_packable_modules"] = [m for m in model.modules() if isinstance(m, (nn.Linear, nn.Conv2d))]
             model.__dict__["_convt_modules"] = [m for m in model.modules() if isinstance(m, nn.ConvTranspose2d) and
                                                 tuple(m.kernel_size) == (2, 2) and tuple(m.stride) == (2, 2)]
-        ws = []
-        for m in cand:
-            w = m.weight
-            if w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and \
-                    (w.dim() == 2 or (w.shape[2] == w.shape[3] and w.shape[2] in (1, 3))):
-                ws.append(w)
-        # the ConvTranspose2d(k=2, s=2) weights of the decoder go into the same launch, as the GEMM matrices they
-        # are used as (else: a permuted copy and a pack of its own per decoder block, forward and backward)
-        wt = [m.weight for m in model.__dict__.get("_convt_modules", ())
-              if m.weight.is_cuda and m.weight.dtype == torch.float32 and m.weight.is_contiguous()]
+        # which weights are packed in which forms depends on the model's tensors only (their addresses change when
+        # it is moved or cast): worked out once per (mode, type, addresses), ~1 ms of list building per step otherwise
+        allw = [m.weight for m in cand] + [m.weight for m in model.__dict__.get("_convt_modules", ())]
+        key = (training, dt, FUSED_MLP, FUSED_MLP_BWD, tuple(w.data_ptr() for w in allw))
+        hit = model.__dict__.get("_pack_plan")
+        if hit is None or hit[0] != key:
+            ws = []
+            for m in cand:
+                w = m.weight
+                if w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and \
+                        (w.dim() == 2 or (w.shape[2] == w.shape[3] and w.shape[2] in (1, 3))):
+                    ws.append(w)
+            # the ConvTranspose2d(k=2, s=2) weights of the decoder go into the same launch, as the GEMM matrices they
+            # are used as (else: a permuted copy and a pack of its own per decoder block, forward and backward)
+            wt = [m.weight for m in model.__dict__.get("_convt_modules", ())
+                  if m.weight.is_cuda and m.weight.dtype == torch.float32 and m.weight.is_contiguous()]
+            # fc1 of the blocks whose MLP branch runs as one launch: 64-channel blocks
+            w64 = []
+            if FUSED_MLP and dt == torch.bfloat16:
+                w64 = [blk.mlp[0].weight for layer in getattr(model, "layers", ()) for blk in layer.blocks
+                       if blk.dim in (96, 192) and blk.mlp[0].weight.shape == (4 * blk.dim, blk.dim) and
+                       any(blk.mlp[0].weight is w for w in ws)]
+            # ... and, for the backward pass of that launch, fc2 in its data-gradient form with 64-channel blocks
+            w64t = []
+            if w64 and training and FUSED_MLP_BWD:
+                w64t = [blk.mlp[3].weight for layer in model.layers for blk in layer.blocks
+                        if any(blk.mlp[0].weight is w for w in w64)]
+            hit = model.__dict__["_pack_plan"] = (key, ws, wt, w64, w64t)
+        _, ws, wt, w64, w64t = hit
         forms = (False, True) if training else (False,)
-        # fc1 of the blocks whose MLP branch runs as one launch: 64-channel blocks
-        w64 = []
-        if FUSED_MLP and dt == torch.bfloat16:
-            w64 = [blk.mlp[0].weight for layer in getattr(model, "layers", ()) for blk in layer.blocks
-                   if blk.dim in (96, 192) and blk.mlp[0].weight.shape == (4 * blk.dim, blk.dim) and
-                   any(blk.mlp[0].weight is w for w in ws)]
-        # ... and, for the backward pass of that launch, fc2 in its data-gradient form with 64-channel blocks
-        w64t = []
-        if w64 and training and FUSED_MLP_BWD:
-            w64t = [blk.mlp[3].weight for layer in model.layers for blk in layer.blocks
-                    if any(blk.mlp[0].weight is w for w in w64)]
         packs = ops.pack_many([(w, tr) for tr in forms for w in ws] +
                               [(w, "convt_t" if tr else "convt") for tr in forms for w in wt] +
                               [(w, "bn64") for w in w64] + [(w, "bn64_t") for w in w64t], dt)
@@ -356,19 +365,34 @@ def _side_stream(device):
     return st
 
 
+class _Fork:
+    """What _on_side needs of the two streams of a backward pass, looked up once: raw handles for the library's
+    fork call and the ids torch's stream switch takes.  (The framework's own route - current_stream(), an Event,
+    record, wait_event, the stream context manager - costs the host ~50 us per job, 72 jobs per step.)"""
+    __slots__ = ("main", "side", "main_raw", "side_raw", "main_ids", "side_ids")
+
+    def __init__(self, main, side):
+        self.main, self.side = main, side
+        self.main_raw, self.side_raw = _lib.c_void_p(main.cuda_stream), _lib.c_void_p(side.cuda_stream)
+        self.main_ids = (main.stream_id, main.device_index, main.device_type)
+        self.side_ids = (side.stream_id, side.device_index, side.device_type)
+
+
 def _on_side(cx, fn, *operands):
     """Runs fn() (weight-gradient launches reading ``operands``) on the side stream, after everything queued
     so far on the current stream; the operands stay allocated until the streams are joined.  Returns fn()'s
     result, whose tensors are marked as used by the main stream too."""
     if cx.side is None:
         return fn()
-    main = torch.cuda.current_stream()
-    ready = torch.cuda.Event()
-    ready.record(main)
+    fk = cx.fork
+    main = fk.main
+    _lib.call("unetk_stream_fork", fk.main_raw, fk.side_raw)
     cx.held.append(operands)
-    with torch.cuda.stream(cx.side):
-        cx.side.wait_event(ready)
+    torch._C._cuda_setStream(*fk.side_ids)
+    try:
         res = fn()
+    finally:
+        torch._C._cuda_setStream(*fk.main_ids)
     for t in (res if isinstance(res, tuple) else (res,)):
         if t is not None:
             t.record_stream(main)
@@ -690,6 +714,7 @@ class _SwinTrainFn(torch.autograd.Function):
         cx = save[0][1]                 # dtype and the packs made by this step's forward
         main = torch.cuda.current_stream()
         cx.side = _side_stream(dout.device) if OVERLAP_WGRAD else None
+        cx.fork = _Fork(main, cx.side) if cx.side is not None else None
         # dgamma / dbeta of the 25 LayerNorms: their partial tables are summed by one launch at the end
         # (not while a HIP graph is being captured: the job table would be uploaded from host memory inside the graph)
         cx.sums = ops.DeferredSums() if (DEFER_LN_SUMS and not torch.cuda.is_current_stream_capturing()) else None
