@@ -516,9 +516,14 @@ def pmc_entry(table, kernel):
     counter passes of the same bench command), or {}."""
     try:
         with open(os.path.join(ROOT, "profiles", table + ".json")) as f:
-            return json.load(f).get(kernel, {})
+            rows = json.load(f)
     except (OSError, ValueError):
         return {}
+    if kernel in rows:
+        return rows[kernel]
+    # (template arguments added since the table was frozen: "name<2, 6>" also finds "name<2, 6, false>")
+    stem = kernel[:-1] if kernel.endswith(">") else kernel
+    return next((v for k, v in rows.items() if k.startswith(stem)), {})
 
 
 class LinearTimer:
