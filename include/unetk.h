@@ -366,6 +366,17 @@ int unetk_window_attn_fwd(const void* qkv, void* out, const float* table, int B,
 int unetk_window_attn_bwd(const void* qkv, const void* dout, void* dqkv, const float* table, float* dtable,
                           float* dtable_partials, int B, int He, int We, int C, int heads, int shift, int use_mask,
                           float scale, int dtype, unetk_stream_t stream);
+/* The same attention for any window side and head dimension (swin_unet_model.py:161-200, 241-269 accept any; the two
+ * entry points above are the MFMA kernels for window 8 / head dimension 32): window side 2...16, head dimension up to
+ * 64, window tokens x head dimension up to 9216 (unetk_window_attn_any_supported).  table: [(2*ws-1)^2][heads];
+ * dtable_partials: [B*nW*heads][(2*ws-1)^2] floats, one row per (window, head) in launch order (window-major, head
+ * fastest): the caller adds the rows of a head. */
+int unetk_window_attn_any_supported(int ws, int head_dim);
+int unetk_window_attn_any_fwd(const void* qkv, void* out, const float* table, int B, int He, int We, int C, int heads,
+                              int ws, int shift, int use_mask, float scale, int dtype, unetk_stream_t stream);
+int unetk_window_attn_any_bwd(const void* qkv, const void* dout, void* dqkv, const float* table, float* dtable_partials,
+                              int B, int He, int We, int C, int heads, int ws, int shift, int use_mask, float scale,
+                              int dtype, unetk_stream_t stream);
 /* dtable_partials: [B * nW * heads][225].  dtable may be null: then the partials are summed later, for every
  * attention layer of the backward pass (:206-219, one table per block) by one launch of
  * unetk_dtable_reduce_batched: jobs (device) = four int64 per job: partials, B * nW, heads, dtable;

@@ -508,6 +508,68 @@ def gen_swin2(swin):
     print("swin2.npz", len(out), "entries")
 
 
+# Configurations whose windows / heads are NOT 8 / 32 (the general attention kernels): name, overrides of the default
+# configuration, (B, H, W) of the input
+SWIN_GEOM_CASES = [
+    ("w4h16", dict(window_size=4, embed_dim=48, depths=[2, 2, 2, 2], decoder_channels=[64, 48, 32, 16]), (2, 64, 64)),
+    ("w7h32", dict(window_size=7, depths=[2, 2, 2, 2], decoder_channels=[128, 64, 32, 16]), (1, 112, 112)),
+    ("w8h64", dict(window_size=8, embed_dim=128, num_heads=[2, 4, 8, 16], depths=[2, 2, 2, 2],
+                   decoder_channels=[128, 64, 32, 16]), (1, 64, 64)),
+]
+
+
+def gen_swin_geom(swin):
+    """The reference with other window sides / head dimensions (swin_unet_model.py:545-554 takes any): eval output in
+    float32, train-mode forward + backward in float64 with DropPath off, oracle == reference asserted first."""
+    out = {}
+    for name, over, (B, H, Wd) in SWIN_GEOM_CASES:
+        cfg = dict(swin_oracle.DEFAULT_CONFIG)
+        cfg.update(over)
+        ref32 = swin.SwinUNet(dict(cfg, use_checkpoint=False))
+        sd = W.fill_state_dict({k: v for k, v in ref32.state_dict().items()}, seed=42)
+        ref32.load_state_dict(sd)
+        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+        x, y, w = W.synthetic_batch(B, 4, H, Wd, seed=42)
+        ref32.eval()
+        with torch.no_grad():
+            r_eval = ref32(x)
+        o_eval, _ = swin_oracle.swin_unet_forward(sd, x, cfg, False)
+        close(o_eval, r_eval, 1e-5, f"swin {name} eval")
+        out[f"{name}.eval_out"] = sub(r_eval, 16384)
+        ref64 = swin.SwinUNet(dict(cfg, use_checkpoint=False)).double()
+        ref64.load_state_dict(sd64)
+        ref64.train()
+        for m in ref64.modules():
+            if isinstance(m, swin.DropPath):
+                m.drop_prob = 0.0
+        xr_ = x.double().clone().requires_grad_(True)
+        r_out = ref64(xr_)
+        tgt = torch.nn.functional.interpolate(y.double(), size=r_out.shape[-2:], mode="bilinear", align_corners=False)
+        r_loss = ((r_out - tgt) ** 2).mean()
+        r_loss.backward()
+        params = {k: v.clone().requires_grad_(True) for k, v in sd64.items()
+                  if v.is_floating_point() and "running_" not in k}
+        full = dict(sd64)
+        full.update(params)
+        xo = x.double().clone().requires_grad_(True)
+        o_out, o_stats = swin_oracle.swin_unet_forward(full, xo, cfg, True, None)
+        ((o_out - tgt) ** 2).mean().backward()
+        close(o_out, r_out, 1e-12, f"swin {name} train out")
+        for k, p in ref64.named_parameters():
+            if k == "final_conv.0.bias":
+                continue
+            close(params[k].grad, p.grad, 1e-9, f"swin {name} grad {k}")
+        close(xo.grad, xr_.grad, 1e-9, f"swin {name} grad input")
+        out[f"{name}.out_shape"] = np.array(r_out.shape)
+        out[f"{name}.train_out"] = sub(r_out, 16384)
+        out[f"{name}.loss"] = np.float64(r_loss.item())
+        out[f"{name}.grad_norms"] = np.array([p.grad.norm().item() for _, p in ref64.named_parameters()])
+        out[f"{name}.param_names"] = np.array([k for k, _ in ref64.named_parameters()])
+        out[f"{name}.grad_input"] = sub(xr_.grad, 4096)
+    np.savez_compressed(os.path.join(HERE, "swin_geom.npz"), **out)
+    print("swin_geom.npz", len(out), "entries")
+
+
 MASKED_UNET = [("small", 1234), ("ragged", 77), ("f48", 5)]      # case of UNET_CASES, torch seed of the draw
 MASKED_SWIN = [("s64", 2, 64, 64, 16), ("s256", 1, 256, 256, 17), ("s24", 2, 24, 24, 3)]
 
@@ -794,7 +856,7 @@ def gen_filter():
 if __name__ == "__main__":
     torch.set_num_threads(8)
     tr, etml, swin, lap = import_reference()
-    which = sys.argv[1:] or ["unet", "loss", "tile", "swin", "step", "patch", "filter", "bf16", "swin2", "step_swin", "masked"]
+    which = sys.argv[1:] or ["unet", "loss", "tile", "swin", "step", "patch", "filter", "bf16", "swin2", "step_swin", "masked", "swin_geom"]
     if "unet" in which:
         gen_unet(tr)
     if "loss" in which:
@@ -813,6 +875,8 @@ if __name__ == "__main__":
         gen_step_swin(swin, etml)
     if "masked" in which:
         gen_masked(tr, swin)
+    if "swin_geom" in which:
+        gen_swin_geom(swin)
     if "patch" in which:
         gen_patch(etml)
     if "filter" in which:

@@ -130,6 +130,50 @@ def test_window_attention_fwd_bwd(dt, case):
     assert rel(dtable, tr_.grad) < TOL[dt] * (2 if dt == torch.bfloat16 else 1)
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("case", [(2, 8, 12, 3, 2, 4, 16), (1, 14, 21, 2, 3, 7, 32), (2, 16, 8, 2, 4, 8, 64),
+                                  (1, 24, 12, 3, 6, 12, 16), (3, 8, 8, 4, 0, 4, 32), (1, 16, 16, 1, 8, 16, 32),
+                                  (1, 12, 12, 2, 6, 12, 64), (2, 6, 9, 5, 1, 3, 24)])
+def test_window_attention_any_geometry(dt, case):
+    """Window sides and head dimensions other than 8 / 32 (the general kernels): forward, the gradient of qkv and of
+    the relative-position table against the oracle's attention in float64, shifted and unshifted."""
+    from unet_amd import ops
+    B, H, Wd, heads, shift, ws, hd = case
+    C = heads * hd
+    t2 = (2 * ws - 1) ** 2
+    assert not ops.window_attn_is_mfma(C, heads, ws)
+    table0 = rnd((t2, heads), 6, torch.float32, 0.5)
+    index = swin_oracle.relative_position_index(ws)
+    qkv = rnd((B, H, Wd, 3 * C), 7, dt, 0.8)
+    dout = rnd((B, H, Wd, C), 8, dt)
+    mask = swin_oracle.shift_mask(H, Wd, ws)
+
+    def ref_attn(h, table):
+        if shift:
+            h = torch.roll(h, (-shift, -shift), (1, 2))
+        wins = swin_oracle._partition(h, ws)
+        Bn, N, _ = wins.shape
+        q, k, v = wins.view(Bn, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
+        a = (q * hd ** -0.5) @ k.transpose(-2, -1)
+        a = a + table[index.view(-1)].view(N, N, heads).permute(2, 0, 1).unsqueeze(0)
+        nW = mask.shape[0]
+        a = (a.view(Bn // nW, nW, heads, N, N) + mask[None, :, None]).view(-1, heads, N, N).softmax(-1)
+        y = swin_oracle._unpartition((a @ v).transpose(1, 2).reshape(Bn, N, C), ws, H, Wd)
+        return torch.roll(y, (shift, shift), (1, 2)) if shift else y
+
+    qr = qkv.double().requires_grad_(True)
+    tr_ = table0.double().requires_grad_(True)
+    ref = ref_attn(qr, tr_)
+    ref.backward(dout.double())
+    table = table0.cuda()
+    out = ops.window_attn_fwd(qkv.to("cuda", dt), table, heads, shift, True, ws=ws)
+    assert rel(out, ref) < TOL[dt]
+    dqkv, dtable = ops.window_attn_bwd(qkv.to("cuda", dt), dout.to("cuda", dt), table, heads, shift, True, ws=ws)
+    assert dtable.shape == (t2, heads)
+    assert rel(dqkv, qr.grad) < TOL[dt] * (2 if dt == torch.bfloat16 else 1)
+    assert rel(dtable, tr_.grad) < TOL[dt] * (2 if dt == torch.bfloat16 else 1)
+
+
 @pytest.mark.parametrize("shape", [(2, 5, 7, 96, 288), (1, 16, 16, 384, 96), (3, 8, 8, 192, 768), (1, 8, 8, 768, 2304),
                                    (2, 9, 4, 64, 96), (1, 24, 24, 1536, 384), (2, 16, 8, 512, 1024), (1, 4, 4, 96, 32)])
 def test_token_linear_gemm(shape):
@@ -311,6 +355,73 @@ def test_swin_train_forward_backward_fp32(golden, name, B, H, Wd):
         assert rel(msd[k], v) < 1e-4, k
 
 
+GEOM_CASES = {      # as tests/golden/make_golden.py SWIN_GEOM_CASES
+    "w4h16": (dict(window_size=4, embed_dim=48, depths=[2, 2, 2, 2], decoder_channels=[64, 48, 32, 16]), (2, 64, 64)),
+    "w7h32": (dict(window_size=7, depths=[2, 2, 2, 2], decoder_channels=[128, 64, 32, 16]), (1, 112, 112)),
+    "w8h64": (dict(window_size=8, embed_dim=128, num_heads=[2, 4, 8, 16], depths=[2, 2, 2, 2],
+                   decoder_channels=[128, 64, 32, 16]), (1, 64, 64)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(GEOM_CASES))
+def test_swin_other_window_and_head_geometries(golden, name):
+    """Configurations the reference accepts beyond its default (swin_unet_model.py:545-554): window 4 with 16-wide
+    heads (48 channels: the linears leave the GEMM path too), window 7 (token grids of 28 / 14 / 7 and a padded 4),
+    window 8 with 64-wide heads.  fp32 eval + train forward / backward against the float64 oracle and the numbers
+    frozen from the reference; bf16 eval inside 2e-2."""
+    from unet_amd.swin import SwinUNet
+    g = golden("swin_geom")
+    over, (B, H, Wd) = GEOM_CASES[name]
+    cfg = dict(swin_oracle.DEFAULT_CONFIG)
+    cfg.update(over)
+    sd = W.fill_state_dict(swin_oracle.swin_template(cfg), seed=42)
+    x, y, _ = W.synthetic_batch(B, 4, H, Wd, seed=42)
+    o_eval, _ = swin_oracle.swin_unet_forward(sd, x, cfg, False)
+    for dt, tol in ((torch.float32, 1e-4), (torch.bfloat16, 2e-2)):
+        m = SwinUNet(cfg, compute_dtype=dt)
+        m.load_state_dict(sd)
+        m = m.cuda().eval()
+        with torch.no_grad():
+            out = m(x.cuda())
+        assert tuple(out.shape) == tuple(g[f"{name}.out_shape"])
+        assert rel(out, o_eval) < tol, (dt, rel(out, o_eval))
+        if dt == torch.float32:
+            assert rel(sub(out, 16384), g[f"{name}.eval_out"]) < 1e-4
+    m = SwinUNet(cfg, compute_dtype=torch.float32)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    m.drop_path_override = [[None, None]] * sum(cfg["depths"])
+    xd = x.cuda().requires_grad_(True)
+    out = m(xd)
+    tgt = F.interpolate(y.double(), size=out.shape[-2:], mode="bilinear", align_corners=False)
+    loss = ((out - tgt.float().cuda()) ** 2).mean()
+    loss.backward()
+    torch.cuda.synchronize()
+    assert rel(sub(out, 16384), g[f"{name}.train_out"]) < 1e-4
+    assert abs(loss.item() - float(g[f"{name}.loss"])) < 1e-4 * float(g[f"{name}.loss"])
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    params = {k: v.clone().requires_grad_(True) for k, v in sd64.items() if v.is_floating_point() and "running_" not in k}
+    full = dict(sd64)
+    full.update(params)
+    xo = x.double().requires_grad_(True)
+    o_out, _ = swin_oracle.swin_unet_forward(full, xo, cfg, True, None)
+    ((o_out - tgt) ** 2).mean().backward()
+    mine = dict(m.named_parameters())
+    assert list(mine) == [str(n) for n in g[f"{name}.param_names"]]
+    names = [n for n in mine if n != "final_conv.0.bias"]
+    flat = torch.cat([mine[n].grad.double().cpu().reshape(-1) for n in names])
+    want = torch.cat([params[n].grad.reshape(-1) for n in names])
+    worst = max((rel(mine[n].grad, params[n].grad), n) for n in names)
+    e_all, e_in = rel(flat, want), rel(xd.grad, xo.grad)
+    print(f"swin {name}: out {rel(out, o_out):.2e} grads {e_all:.2e} worst {worst[0]:.2e} {worst[1]} dx {e_in:.2e}")
+    assert rel(out, o_out) < 1e-4
+    assert e_all < 2e-2 and e_in < 2e-2 and worst[0] < 1e-1, (e_all, e_in, worst)
+    norms = np.array([p.grad.double().norm().item() for n, p in mine.items()])
+    keep = np.array([n != "final_conv.0.bias" for n in mine])
+    assert rel(norms[keep], g[f"{name}.grad_norms"][keep]) < 2e-2
+    assert rel(sub(xd.grad, 4096), g[f"{name}.grad_input"]) < 2e-2
+
+
 @pytest.mark.parametrize("name,B,H,Wd", [("s64", 2, 64, 64), ("s128x64", 1, 128, 64), ("s256", 1, 256, 256)])
 def test_swin_train_forward_backward_bf16(golden, name, B, H, Wd):
     """bf16 storage (the benchmarked path, including the bf16-only fused weight + bias gradient of the
@@ -417,8 +528,13 @@ def test_swin_seeded_droppath_and_errors(golden):
     with pytest.raises(RuntimeError):
         m.cpu()(torch.zeros(1, 4, 64, 64))
     from unet_amd.swin import SwinUNet
+    SwinUNet(dict(cfg, window_size=7))                      # (other windows: the general attention kernels)
     with pytest.raises(ValueError):
-        SwinUNet(dict(cfg, window_size=7))
+        SwinUNet(dict(cfg, window_size=20))                 # beyond them
+    with pytest.raises(ValueError):
+        SwinUNet(dict(cfg, embed_dim=384))                  # 128-wide heads
+    with pytest.raises(ValueError):
+        SwinUNet(dict(cfg, drop_rate=0.1))
 
 
 @pytest.mark.parametrize("C,ntok", [(96, 4096), (192, 1000), (384, 333), (768, 64)])

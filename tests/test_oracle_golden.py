@@ -208,6 +208,37 @@ def test_swin_oracle_matches_golden_full_size_and_resized_skip(golden, name, B, 
     assert rel(norms[keep], g[f"{name}.grad_norms"][keep]) < 1e-8
 
 
+@pytest.mark.parametrize("name", ["w4h16", "w7h32", "w8h64"])
+def test_swin_oracle_other_geometries_match_golden(golden, name):
+    """swin_geom.npz: the reference with window sides / head dimensions other than 8 / 32 (frozen by
+    make_golden.py gen_swin_geom: eval in float32, train forward + backward in float64)."""
+    from tests.test_gpu_swin import GEOM_CASES
+    g = golden("swin_geom")
+    over, (B, H, Wd) = GEOM_CASES[name]
+    cfg = dict(swin_oracle.DEFAULT_CONFIG)
+    cfg.update(over)
+    sd = W.fill_state_dict(swin_oracle.swin_template(cfg), seed=42)
+    x, y, _ = W.synthetic_batch(B, 4, H, Wd, seed=42)
+    o, _ = swin_oracle.swin_unet_forward(sd, x, cfg, False)
+    assert tuple(o.shape) == tuple(g[f"{name}.out_shape"])
+    assert rel(sub(o, 16384), g[f"{name}.eval_out"]) < 1e-5
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    params = {k: v.clone().requires_grad_(True) for k, v in sd64.items()
+              if v.is_floating_point() and "running_" not in k}
+    full = dict(sd64)
+    full.update(params)
+    out, _ = swin_oracle.swin_unet_forward(full, x.double(), cfg, True, None)
+    tgt = torch.nn.functional.interpolate(y.double(), size=out.shape[-2:], mode="bilinear", align_corners=False)
+    loss = ((out - tgt) ** 2).mean()
+    loss.backward()
+    assert abs(loss.item() - g[f"{name}.loss"]) < 1e-9
+    assert rel(sub(out, 16384), g[f"{name}.train_out"]) < 1e-10
+    names = [str(s) for s in g[f"{name}.param_names"]]
+    norms = np.array([params[k].grad.norm().item() for k in names])
+    keep = np.array([k != "final_conv.0.bias" for k in names])
+    assert rel(norms[keep], g[f"{name}.grad_norms"][keep]) < 1e-8
+
+
 def test_swin_training_step_oracle_matches_golden(golden):
     """The Swin trainer's step (swin_unet_model.py:809-823) restated: resize to the label, 'tid_gradient' loss,
     clip, AdamW(1e-4, 0.05), against the step frozen from the reference's own modules and torch.optim.AdamW."""

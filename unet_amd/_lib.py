@@ -116,6 +116,9 @@ _SIGNATURES = {
     "unetk_window_attn_fwd": (I, [P, P, P, I, I, I, I, I, I, I, F, I, P]),
     "unetk_window_attn_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, F, I, P]),
     "unetk_dtable_reduce_batched": (I, [P, I, I, P]),
+    "unetk_window_attn_any_supported": (I, [I, I]),
+    "unetk_window_attn_any_fwd": (I, [P, P, P, I, I, I, I, I, I, I, I, F, I, P]),
+    "unetk_window_attn_any_bwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, P]),
 }
 
 _lib = None

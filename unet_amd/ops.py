@@ -844,21 +844,38 @@ def pixel_shuffle(tmp, cat, bias, Co, backward=False):
          dtype_code(tmp.dtype), stream())
 
 
-def window_attn_fwd(qkv, table, heads, shift, use_mask):
+def window_attn_is_mfma(C, heads, ws):
+    """Window 8 with head dimension 32: the MFMA kernels; anything else goes to the general ones."""
+    return ws == 8 and C == heads * 32
+
+
+def window_attn_fwd(qkv, table, heads, shift, use_mask, ws=8):
     B, He, We, C3 = qkv.shape
     C = C3 // 3
     out = torch.empty((B, He, We, C), dtype=qkv.dtype, device=qkv.device)
+    if not window_attn_is_mfma(C, heads, ws):
+        call("unetk_window_attn_any_fwd", ptr(qkv), ptr(out), ptr(table), B, He, We, C, heads, ws, shift,
+             1 if use_mask else 0, (C // heads) ** -0.5, dtype_code(qkv.dtype), stream())
+        return out
     call("unetk_window_attn_fwd", ptr(qkv), ptr(out), ptr(table), B, He, We, C, heads, shift,
          1 if use_mask else 0, (C // heads) ** -0.5, dtype_code(qkv.dtype), stream())
     return out
 
 
-def window_attn_bwd(qkv, dout, table, heads, shift, use_mask, defer=None):
-    """Returns (dqkv, dtable (225, heads)).  defer: a DeferredSums that sums the table's partials later."""
+def window_attn_bwd(qkv, dout, table, heads, shift, use_mask, defer=None, ws=8):
+    """Returns (dqkv, dtable ((2*ws-1)**2, heads)).  defer: a DeferredSums that sums the table's partials later
+    (window 8 / head dimension 32 only; the general kernels' partials are added here)."""
     B, He, We, C3 = qkv.shape
     C = C3 // 3
     dev = qkv.device
     dqkv = torch.empty_like(qkv)
+    if not window_attn_is_mfma(C, heads, ws):
+        t2 = (2 * ws - 1) ** 2
+        nwin = B * (He // ws) * (We // ws)
+        partials = torch.empty((nwin, heads, t2), dtype=torch.float32, device=dev)
+        call("unetk_window_attn_any_bwd", ptr(qkv), ptr(dout), ptr(dqkv), ptr(table), ptr(partials), B, He, We, C, heads,
+             ws, shift, 1 if use_mask else 0, (C // heads) ** -0.5, dtype_code(qkv.dtype), stream())
+        return dqkv, partials.sum(0).t().contiguous()
     nblk = B * (He // 8) * (We // 8) * heads
     partials = torch.empty((nblk, 225), dtype=torch.float32, device=dev)
     dtable = torch.empty((225, heads), dtype=torch.float32, device=dev)

@@ -125,8 +125,8 @@ class SwinUNet(nn.Module):
         self.num_layers = len(self.depths)
         self.patch_norm = True
         self.compute_dtype = compute_dtype
-        if self.window_size != _WS:
-            raise ValueError(f"the window-attention kernel implements window_size {_WS}, got {self.window_size}")
+        # (window 8 with head dimension 32 - the reference configuration - runs on the MFMA attention kernels,
+        # any other geometry the general kernels take on those: checked per stage below)
         if self.drop_rate != 0.0 or self.attn_drop_rate != 0.0:
             raise ValueError("element dropout inside attention / MLP (drop_rate, attn_drop_rate) is not "
                              "implemented; the reference configuration uses 0.0")
@@ -138,8 +138,12 @@ class SwinUNet(nn.Module):
         self.layers = nn.ModuleList()
         dim = self.embed_dim_val
         for i in range(self.num_layers):
-            if dim // self.num_heads[i] != 32 or dim % self.num_heads[i]:
-                raise ValueError("the window-attention kernel implements head dimension 32")
+            if dim % self.num_heads[i] or not _lib.load().unetk_window_attn_any_supported(
+                    int(self.window_size), dim // self.num_heads[i]):
+                raise ValueError(f"window attention with window_size {self.window_size} and head dimension "
+                                 f"{dim / self.num_heads[i]:g} (stage {i}: {dim} channels, {self.num_heads[i]} heads) is "
+                                 "not implemented: window side 2...16, head dimension up to 64, window tokens x head "
+                                 "dimension up to 9216")
             self.layers.append(BasicLayer(
                 dim, self.depths[i], self.num_heads[i], self.window_size, self.mlp_ratio, True, self.drop_rate,
                 self.attn_drop_rate, dpr[sum(self.depths[:i]):sum(self.depths[:i + 1])],
@@ -437,11 +441,11 @@ def _linear_bwd(x, dy, w, cx, grads, wname, bname, need_dx=True, gelu_grad_of=No
     return None
 
 
-def _check_grid(H, W):
+def _check_grid(H, W, ws=_WS):
     for n in (H, W):
-        if n > _WS and n % _WS:
+        if n > ws and n % ws:
             raise RuntimeError(f"shape is invalid for window partition: a {H}x{W} token grid is not a multiple "
-                               f"of the window size {_WS}")
+                               f"of the window size {ws}")
 
 
 def _pad_tokens(t, He, We):
@@ -456,15 +460,16 @@ def _pad_tokens(t, He, We):
 def _block_fwd(blk, pre, x, keep1, keep2, cx, save):
     """One SwinTransformerBlock (:305-374) on tokens x (B,H,W,C)."""
     B, H, W, C = x.shape
-    _check_grid(H, W)
-    He, We = max(H, _WS), max(W, _WS)
+    ws = blk.window_size
+    _check_grid(H, W, ws)
+    He, We = max(H, ws), max(W, ws)
     padded = (He, We) != (H, W)
     a = blk.attn
     ln1, m1, r1 = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
     ln1p = _pad_tokens(ln1, He, We)
     qkv = _linear(ln1p, a.qkv.weight, a.qkv.bias, cx)
     # the shift mask is built for every stage and handed to every block, shifted or not (:458-484)
-    att = ops.window_attn_fwd(qkv, a.relative_position_bias_table, a.num_heads, blk.shift_size, True)
+    att = ops.window_attn_fwd(qkv, a.relative_position_bias_table, a.num_heads, blk.shift_size, True, ws=ws)
     if not padded:
         x1 = _linear(att, a.proj.weight, a.proj.bias, cx, resid=x, keep=keep1)
     else:
@@ -541,7 +546,7 @@ def _block_bwd(blk, pre, ctx, dx2, cx, grads, db2=None, keep_next=None):
     dbp = _pad_tokens(db, He, We) if padded else db
     datt = _linear_bwd(att, dbp, a.proj.weight, cx, grads, pre + "attn.proj.weight", pre + "attn.proj.bias")
     dqkv, grads[pre + "attn.relative_position_bias_table"] = ops.window_attn_bwd(
-        qkv, datt, a.relative_position_bias_table, a.num_heads, blk.shift_size, True, defer=cx.sums)
+        qkv, datt, a.relative_position_bias_table, a.num_heads, blk.shift_size, True, defer=cx.sums, ws=blk.window_size)
     dln1 = _linear_bwd(ln1p, dqkv, a.qkv.weight, cx, grads, pre + "attn.qkv.weight", pre + "attn.qkv.bias")
     if padded:
         dln1 = dln1[:, :H, :W].contiguous()
