@@ -238,7 +238,13 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     const int ch = phase / KS, ky = phase - ch * KS;
     char* dst = lds + NHB * HBUF + (RING3 ? phase % 3 : (phase & 1)) * WBUF;
     const T* wsrc = wp + ((((long)nb * a.nchunks + ch) * TAPS + ky * KS) * BN) * KC + w_rel;
-    for (int i = wave; i < WINSTR; i += 4) glds16(wsrc + i * (1024 / (int)sizeof(T)), dst + i * 1024);
+    // (unrolled: the trip count depends on the wave only through the last piece)
+    constexpr int WPWV = (WINSTR + 3) / 4;
+#pragma unroll
+    for (int k = 0; k < WPWV; ++k) {
+      const int i = wave + 4 * k;
+      if (4 * k + 3 < WINSTR || i < WINSTR) glds16(wsrc + i * (1024 / (int)sizeof(T)), dst + i * 1024);
+    }
   };
 
   const int nphase = a.nchunks * KS;
@@ -293,13 +299,12 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     };
     bool halo_fly = false;
     auto open_phase = [&](int q, int vm_keep) {
-      // q: the phase whose operands must have landed; afterwards the DMA of phase q+1 goes out
-      switch (vm_keep) {
-#define UNETK_WLB(N) case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-        UNETK_WLB(1) UNETK_WLB(2) UNETK_WLB(3) UNETK_WLB(4) UNETK_WLB(5) UNETK_WLB(6) UNETK_WLB(7) UNETK_WLB(8)
-        default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-#undef UNETK_WLB
-      }
+      // q: the phase whose operands must have landed; afterwards the DMA of phase q+1 goes out.  vm_keep is 0 or
+      // this wave's halo pieces, of which there are only two possible counts: two compares instead of a switch
+      constexpr int HP_HI = (HINSTR + 3) / 4, HP_LO = HINSTR / 4;
+      if (vm_keep == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else if (vm_keep == HP_HI) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(HP_HI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(HP_LO > 0 ? HP_LO : 1) : "memory");
       if (q + 1 < nphase) issue_w(q + 1);
     };
     auto chunk = [&](auto parc, int ch) {
