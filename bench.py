@@ -838,14 +838,17 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
+    # stdout carries the one JSON line and nothing else: whatever a library prints there meanwhile (RCCL's version
+    # banner under NCCL_DEBUG=VERSION, for one) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if multi(world):
         import torch.distributed as dist
         if world == 1 and "MASTER_ADDR" not in os.environ:       # the one-rank rehearsal started by hand
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), RANK="0", WORLD_SIZE="1")
-        # (a box may export NCCL_DEBUG=VERSION: RCCL's banner then goes to stderr, stdout carries the one JSON line)
-        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
         dist.init_process_group("nccl", device_id=dev)
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     runners = {"train": run_train, "swin": run_swin, "predict": run_predict}
@@ -864,7 +867,8 @@ def main():
         if rank == 0:
             line.update(extra)
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if multi(world):
         dist.barrier()
         dist.destroy_process_group()
