@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Token GEMM with 96- against 192-channel blocks on the stage-2/3 shapes: tools/bench_gemm_bn.py"""
+"""Token GEMM (96-channel blocks) on the stage-2/3 shapes of the Swin encoder at batch 64, checked against torch:
+tools/bench_gemm_bn.py   (UNETK_AB_LIB=<other build> to time a variant)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -38,7 +39,7 @@ for side, C in ((16, 384), (8, 768)):
         w = (torch.randn(co, ci, device="cuda") * 0.05).contiguous()
         outs = {}
         ts = {}
-        for bn in (96, 96):
+        for bn in (96,):
             d = pack(w, bn)
             out = torch.empty(B, side, side, co, dtype=dt, device="cuda")
             ts[bn] = timeit(lambda: run(x, d, co, bn, out))
