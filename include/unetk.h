@@ -93,6 +93,16 @@ int unetk_conv_fwd_split(const void* in, int ldin, const void* wpacked, void* ou
 int unetk_conv_fwd_cat(const void* in, int ldin, int Ci1, const void* in2, int ldin2, const void* wpacked, void* out,
                        int ldout, int B, int H, int W, int Ci, int Co, int bn, int dtype, float* stats,
                        const float* ep_scale, const float* ep_shift, int act, unetk_stream_t stream);
+/* Data gradient of a 3x3 conv (weights packed transposed, as for unetk_conv_fwd) whose result g is the gradient of
+ * the activation relu(y*scale+shift) of the BatchNorm in front (training.py:523-529, the second conv of a block in
+ * the backward): besides storing g (dense, Co channels) the launch leaves the two per-channel sums that BatchNorm's
+ * backward needs, partials[unetk_conv_num_tiles(B,H,W,3)][2][Co] = sum of dz and sum of dz*(y-mean)*invstd with
+ * dz = g where y*scale+shift > 0, formed from the values as stored; unetk_bn_act_bwd_presummed takes them in place of
+ * its own reduction pass over g and y.  bfloat16 with a channel block of 64 or 96 (see ..._supported). */
+int unetk_conv_bwd_data_bnsums_supported(int Co, int bn, int dtype);
+int unetk_conv_bwd_data_bnsums(const void* dy, int lddy, const void* wpackedT, void* out, int B, int H, int W, int Ci,
+                               int Co, int bn, int dtype, const void* y, int ldy, const float* scale, const float* shift,
+                               const float* mean, const float* invstd, float* partials, unetk_stream_t stream);
 /* ... and its weight gradient (workspace as unetk_conv_wgrad_workspace_bytes for the whole Ci). */
 int unetk_conv_wgrad_cat(const void* in, int ldin, int Ci1, const void* in2, int ldin2, const void* dy, int lddy,
                          float* dw, int B, int H, int W, int Ci, int Co, int dtype, void* workspace,
@@ -200,6 +210,12 @@ int unetk_bn_act_bwd(const void* g, const void* y, void* dy, int B, int H, int W
                      const float* scale, const float* shift, const float* mean, const float* invstd,
                      const float* keep, int relu, float* dgamma, float* dbeta, int accumulate,
                      float* partials, float* sums, int dtype, unetk_stream_t stream);
+/* Same (ReLU, no keep factors) with the reduction already done: partials [nparts][2][C] as unetk_conv_bwd_data_bnsums
+ * leaves them.  sums as above. */
+int unetk_bn_act_bwd_presummed(const void* g, const void* y, void* dy, int B, int H, int W, int C, const float* scale,
+                               const float* shift, const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                               int accumulate, const float* partials, int nparts, float* sums, int dtype,
+                               unetk_stream_t stream);
 /* Same with a rank-one gradient that is never stored: g[b,y,x,c] = gpix[b,y,x] * gchan[c] (rounded to the
  * compute type as the stored tensor would be).  The gradient of the last activation of the UNet is of this
  * form: dout (B,1,H,W) times the weight of the final 1x1 conv (training.py:482, 520). */

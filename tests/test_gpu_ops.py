@@ -248,6 +248,45 @@ def test_bn_bwd_with_the_pool_gradient_formed_inside(dt, shape):
         assert torch.equal(dy0, dy1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 32, 96, 96), (3, 19, 23, 64, 128), (1, 16, 16, 192, 96), (2, 7, 40, 96, 64),
+                                   (5, 33, 17, 288, 192)])
+def test_bn_bwd_sums_from_the_data_gradient_conv(shape):
+    """The data-gradient conv that leaves BatchNorm-backward's two sums beside its output
+    (unetk_conv_bwd_data_bnsums + unetk_bn_act_bwd_presummed): the gradient itself has the same bits as the plain
+    launch, the sums agree with the separate reduction pass (another summation order: 1e-5 of their scale), and so
+    does what the BatchNorm backward makes of them.  Ragged image sizes and several channel blocks included."""
+    from unet_amd import ops
+    dt = torch.bfloat16
+    B, H, W, C, C2 = shape              # the block's first conv has C outputs, its second conv C -> C2
+    y = nhwc((rnd((B, C, H, W), 50, dt) * 1.5 + 0.3), dt)
+    stats = torch.stack([y.float().sum((0, 1, 2)), (y.float() ** 2).sum((0, 1, 2))]).view(1, 2, C).contiguous()
+    gamma, beta = (torch.rand(C) + 0.5).cuda(), (torch.randn(C) * 0.2).cuda()
+    mean, invstd, sc, sh = ops.bn_finalize(stats, B * H * W, gamma, beta, None, None)
+    w = torch.randn(C2, C, 3, 3, generator=torch.Generator().manual_seed(51)) * 0.1
+    pwt = ops.PackedConv(w.cuda(), dt, transpose=True)
+    assert ops.conv_bwd_data_bnsums_supported(pwt, dt)
+    dy2 = nhwc(rnd((B, C2, H, W), 52, dt), dt)
+    g0, _ = ops.conv_fwd(dy2, pwt)
+    g1, parts = ops.conv_bwd_data_bnsums(dy2, pwt, y, sc, sh, mean, invstd)
+    assert torch.equal(g0, g1)
+    dz = torch.where(torch.addcmul(sh, y.float(), sc) > 0, g0.float(), torch.zeros((), device="cuda")).double()
+    want0 = dz.sum((0, 1, 2))
+    want1 = (dz * ((y.float() - mean) * invstd).double()).sum((0, 1, 2))
+    got = parts.double().sum(0)
+    scale0 = dz.abs().sum((0, 1, 2)).max().item()
+    assert (got[0] - want0).abs().max().item() < 1e-5 * scale0
+    assert (got[1] - want1).abs().max().item() < 2e-5 * scale0
+    dya, dga, dba = ops.bn_act_bwd(g0, y, sc, sh, mean, invstd, None, relu=True)
+    dyb, dgb, dbb = ops.bn_act_bwd(g1, y, sc, sh, mean, invstd, None, relu=True, presummed=parts)
+    assert (dga - dgb).abs().max().item() < 2e-5 * scale0 and (dba - dbb).abs().max().item() < 1e-5 * scale0
+    # the apply pass rounds to bfloat16: a last-place difference in a coefficient may flip a rounding here and there
+    diff = (dya.float() - dyb.float()).abs()
+    assert diff.max().item() <= 2 ** -7 * dya.float().abs().max().item()
+    assert (diff > 0).float().mean().item() < 1e-2
+    with pytest.raises(ValueError):
+        ops.bn_act_bwd(g1, y, sc, sh, mean, invstd, torch.ones(B, C, device="cuda"), relu=True, presummed=parts)
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("hw", [((8, 8), (16, 16)), ((6, 9), (12, 18)), ((12, 18), (25, 36)), ((1, 1), (3, 3)),
                                 ((3, 5), (7, 11)), ((1, 1), (2, 2)), ((2, 3), (4, 6)), ((1, 5), (2, 10)),

@@ -43,5 +43,17 @@ for name, hw, ci, co in layers:
     ws = torch.empty(ops._lib.load().unetk_conv_wgrad_workspace_bytes(B, hw, hw, ci, co, 3, 1), dtype=torch.uint8, device="cuda")
     t_w = timeit(lambda: ops.conv_wgrad(x, dy, ci, co, 3, workspace=ws))
     tot["fwd"] += t_f; tot["dgrad"] += t_d; tot["wgrad"] += t_w
+    if os.environ.get("BNSUMS") and ci == co and ops.conv_bwd_data_bnsums_supported(pwt, dt):
+        # the data gradient that also leaves the next BatchNorm backward's sums, and that pass with / without them
+        y = torch.randn(B, hw, hw, ci, device="cuda").to(dt)
+        C = ci
+        st = torch.stack([y.float().sum((0, 1, 2)), (y.float() ** 2).sum((0, 1, 2))]).view(1, 2, C).contiguous()
+        mean, invstd, sc, sh = ops.bn_finalize(st, B * hw * hw, torch.ones(C, device="cuda"), torch.zeros(C, device="cuda"), None, None)
+        g, parts = ops.conv_bwd_data_bnsums(dy, pwt, y, sc, sh, mean, invstd)
+        t_d2 = timeit(lambda: ops.conv_bwd_data_bnsums(dy, pwt, y, sc, sh, mean, invstd))
+        t_b = timeit(lambda: ops.bn_act_bwd(g, y, sc, sh, mean, invstd))
+        t_b2 = timeit(lambda: ops.bn_act_bwd(g, y, sc, sh, mean, invstd, presummed=parts))
+        tot["bnsums"] = tot.get("bnsums", 0) + (t_d2 - t_d) - (t_b - t_b2)
+        print(f"         dgrad+sums {t_d2:7.3f} ms (+{t_d2 - t_d:6.3f})   BN backward {t_b:7.3f} -> {t_b2:7.3f} ms ({t_b2 - t_b:+6.3f})", flush=True)
     print(f"{name:8s} {hw:4d}^2 {ci:5d}->{co:4d}  fwd {t_f:7.3f} ms {fl/t_f/1e9:7.0f} TF/s | dgrad {t_d:7.3f} ms {fl/t_d/1e9:7.0f} | wgrad {t_w:7.3f} ms {fl/t_w/1e9:7.0f}", flush=True)
 print(tot)

@@ -44,6 +44,8 @@ _SIGNATURES = {
     "unetk_conv_fwd_split": (I, [P, I, P, P, I, P, I, I, I, I, I, I, I, I, I, I, P, P, P, I, P, I, P, P]),
     "unetk_conv_wgrad_workspace_bytes": (L, [I, I, I, I, I, I, I]),
     "unetk_conv_fwd_cat": (I, [P, I, I, P, I, P, P, I, I, I, I, I, I, I, I, P, P, P, I, P]),
+    "unetk_conv_bwd_data_bnsums_supported": (I, [I, I, I]),
+    "unetk_conv_bwd_data_bnsums": (I, [P, I, P, P, I, I, I, I, I, I, I, P, I, P, P, P, P, P, P]),
     "unetk_conv_wgrad_cat": (I, [P, I, I, P, I, P, I, P, I, I, I, I, I, I, P, L, I, P]),
     "unetk_conv_wgrad": (I, [P, I, P, I, P, I, I, I, I, I, I, I, P, L, I, P]),
     "unetk_linear_wgrad_workspace_bytes": (L, [L, I, I, I]),
@@ -77,6 +79,7 @@ _SIGNATURES = {
     "unetk_reduce_num_partials": (I, [L]),
     "unetk_bn_act_bwd": (I, [P, P, P, I, I, I, I, P, P, P, P, P, I, P, P, I, P, P, I, P]),
     "unetk_bn_act_bwd_rank1": (I, [P, P, P, P, I, I, I, I, P, P, P, P, P, I, P, P, I, P, P, I, P]),
+    "unetk_bn_act_bwd_presummed": (I, [P, P, P, I, I, I, I, P, P, P, P, P, P, I, P, I, P, I, P]),
     "unetk_bn_act_bwd_pool": (I, [P, P, P, I, P, P, I, I, I, I, P, P, P, P, P, I, P, P, I, P, P, I, P]),
     "unetk_pool_bwd": (I, [P, P, P, P, I, P, I, I, I, I, I, P]),
     "unetk_upsample_concat_fwd": (I, [P, I, I, I, P, I, I, P, I, I, I, I, P]),

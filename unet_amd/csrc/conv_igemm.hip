@@ -51,6 +51,17 @@ struct ConvArgs {
   int head_co;
   const void* resid;       // residual (same layout as out, ld = ldres) or null
   const float* resid_keep; // per-sample scale applied to the conv result before the add, or null
+  // BatchNorm-backward sums of the layer whose input gradient this launch produces (BST instantiations, data
+  // gradient of the second conv of a block): with y that layer's conv output and z = y*scale+shift,
+  // partials[tile][0][c] = sum over the tile's pixels of dz, [1][c] = sum of dz*(y-mean)*invstd, dz = (z > 0 ? out : 0)
+  // on the values as they are stored: what channel_reduce_kernel's first mode forms from the stored tensors.
+  const void* bs_y;
+  const float* bs_scale;
+  const float* bs_shift;
+  const float* bs_mean;
+  const float* bs_invstd;
+  float* bs_partials;
+  int ldbs;
   const void* in2;         // input channels >= Ci1 come from here (ld = ldin2, renumbered from 0), or null:
   int ldin2, Ci1;          // the operand is the channel concatenation [in | in2] without ever being stored
   int ldin, ldout, ldres, ldout2, split;
@@ -84,7 +95,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
-template <typename T, int NT, int KS, bool HDB, bool FUSE, bool TWO>
+template <typename T, int NT, int KS, bool HDB, bool FUSE, bool TWO, bool BST = false>
 __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
   using M = MMA<T>;
   constexpr int KC = M::KC;
@@ -111,7 +122,14 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
   constexpr int MAIN_BYTES = NHB * HBUF + NWB * WBUF;
   constexpr int STAGE_BYTES = 4 * 16 * BN * (int)sizeof(T);
   constexpr int RED_BYTES = 4 * 2 * BN * (int)sizeof(float);
-  constexpr int LDS_BYTES = MAIN_BYTES > STAGE_BYTES + RED_BYTES ? MAIN_BYTES : STAGE_BYTES + RED_BYTES;
+  // (BST) the tile of y behind them: 4 waves x 4 rows of 16 pixels x BN channels, whole 1 KiB DMA pieces a row
+  static_assert(!BST || KS == 3, "the BatchNorm-backward sums are built for the 3x3 data gradient");
+  constexpr int YPP = BN / EPP;                       // 16-byte parts per pixel
+  constexpr int YNIT = (16 * YPP + 63) / 64;          // DMA pieces per tile row
+  constexpr int YST_OFF = (STAGE_BYTES + RED_BYTES + 1023) / 1024 * 1024;
+  constexpr int YST_BYTES = BST ? 4 * 4 * YNIT * 1024 : 0;
+  constexpr int EPI_BYTES = BST ? YST_OFF + YST_BYTES : STAGE_BYTES + RED_BYTES;
+  constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
   __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
   // per-wave statistics scratch aliases the operand area (behind the epilogue staging tiles)
   float (*red)[2][BN] = reinterpret_cast<float (*)[2][BN]>(lds + STAGE_BYTES);
@@ -463,6 +481,20 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
 
   const bool tile_full = (KS == 3) ? (y0 + 16 <= a.H && x0 + 16 <= a.W) : (p0 + 256 <= npix);
   __syncthreads();   // every wave is done reading the operand tiles: LDS is reused from here on
+  char* const yst = lds + YST_OFF + wave * (4 * YNIT * 1024);
+  if constexpr (BST) {
+    // the wave's four rows of y (16 pixels x BN channels each) by LDS-DMA, in flight under the store pass below
+    const T* ysrc = reinterpret_cast<const T*>(a.bs_y);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int k = 0; k < YNIT; ++k) {
+        const int part = lane + 64 * k;
+        const int pc = part / YPP, cp = part - pc * YPP;
+        const bool ok = part < 16 * YPP && rowvalid[i] && (KS == 3 ? (x0 + pc) < a.W : true) && n0 + cp * EPP < a.Co;
+        glds16(ok ? ysrc + (pixbase[i] + pc) * a.ldbs + n0 + cp * EPP : zero, yst + (i * YNIT + k) * 1024);
+      }
+  }
   if (a.stats != nullptr) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -659,11 +691,49 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
       }
     }
   }
+  if constexpr (BST) {
+    // (the accumulators still hold the output: a data-gradient launch has no scale, shift or activation)
+    __builtin_amdgcn_s_waitcnt(0x0070);        // vmcnt(0): this wave's rows of y have landed (each wave reads its own)
+    __syncthreads();                           // ... and every wave is done with red[] and the staging tiles
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int c = n0 + j * 16 + cl;
+      const float bsc = c < a.Co ? a.bs_scale[c] : 0.f, bsh = c < a.Co ? a.bs_shift[c] : 0.f;
+      const float bmu = c < a.Co ? a.bs_mean[c] : 0.f, bis = c < a.Co ? a.bs_invstd[c] : 0.f;
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          // the tile row's image is lane-linear in 16-byte parts: pixel pc, part cp at byte (pc*YPP + cp)*16
+          const T yraw = *reinterpret_cast<const T*>(yst + i * YNIT * 1024 + ((4 * pg + r) * BN + j * 16 + cl) * (int)sizeof(T));
+          const float yv = to_f32(yraw);
+          float dz = to_f32(from_f32<T>(acc[i][j][r]));
+          if (!(fmaf(yv, bsc, bsh) > 0.f) || !pixel_valid(i, r)) dz = 0.f;
+          s += dz;
+          q = fmaf(dz, (yv - bmu) * bis, q);
+        }
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      q += __shfl_xor(q, 16, 64);
+      q += __shfl_xor(q, 32, 64);
+      if (pg == 0) {
+        red[wave][0][j * 16 + cl] = s;
+        red[wave][1][j * 16 + cl] = q;
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < a.Co) {
+      float* st = a.bs_partials + (long)tile * 2 * a.Co;
+      st[n0 + tid] = red[0][0][tid] + red[1][0][tid] + red[2][0][tid] + red[3][0][tid];
+      st[a.Co + n0 + tid] = red[0][1][tid] + red[1][1][tid] + red[2][1][tid] + red[3][1][tid];
+    }
+  }
 }
 
-template <typename T, int NT, int KS, bool FUSE = false, bool TWO = false>
+template <typename T, int NT, int KS, bool FUSE = false, bool TWO = false, bool BST = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_igemm_kernel(ConvArgs a) {
-  conv_igemm_body<T, NT, KS, true, FUSE, TWO>(a);
+  conv_igemm_body<T, NT, KS, true, FUSE, TWO, BST>(a);
 }
 
 // Narrow layers move more bytes per flop than the MFMA-bound wide ones: they trade the second halo
@@ -1618,6 +1688,14 @@ int launch_conv(ConvArgs a, int bn, hipStream_t stream) {
   a.nby = cdiv(a.Co, bn);
   dim3 grid((unsigned)(8 * a.tiles_per_xcd * a.nby));
   if constexpr (KS == 3 && sizeof(T) == 2) {
+    if (a.bs_partials != nullptr) {    // data gradient + the next BatchNorm backward's sums (arguments checked by the entry point)
+      if (bn == 96) hipLaunchKernelGGL((conv_igemm_kernel<T, 6, KS, false, false, true>), grid, dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL((conv_igemm_kernel<T, 4, KS, false, false, true>), grid, dim3(256), 0, stream, a);
+      UNETK_CHECK_LAUNCH();
+      return UNETK_OK;
+    }
+  }
+  if constexpr (KS == 3 && sizeof(T) == 2) {
     if (a.nby == 3 && a.stats == nullptr && a.ep_scale == nullptr && a.ep_shift == nullptr && a.pooled == nullptr &&
         a.head_out == nullptr && (a.out2 == nullptr || a.split % 48 == 0)) {
       // three 48-channel output blocks over a narrow input (the data gradient of the 144 -> 48 layer)
@@ -1769,7 +1847,8 @@ static int conv_fwd_impl(const void* in, int ldin, const void* in2, int ldin2, i
                          int ldout, void* out2, int ldout2, int split, void* pooled, const float* head_w,
                          const float* head_b, float* head_out, int head_co, int B, int H, int W, int Ci, int Co, int ks,
                          int bn, int dtype, float* stats, const float* ep_scale, const float* ep_shift, int act,
-                         const void* resid, int ldres, const float* resid_keep, hipStream_t stream);
+                         const void* resid, int ldres, const float* resid_keep, hipStream_t stream,
+                         const ConvArgs* bnsums = nullptr);
 
 int unetk_conv_fwd_fused(const void* in, int ldin, const void* wpacked, void* out, int ldout, void* out2,
                          int ldout2, int split, void* pooled, const float* head_w, const float* head_b,
@@ -1798,7 +1877,8 @@ static int conv_fwd_impl(const void* in, int ldin, const void* in2, int ldin2, i
                          int ldout, void* out2, int ldout2, int split, void* pooled, const float* head_w,
                          const float* head_b, float* head_out, int head_co, int B, int H, int W, int Ci, int Co, int ks,
                          int bn, int dtype, float* stats, const float* ep_scale, const float* ep_shift, int act,
-                         const void* resid, int ldres, const float* resid_keep, hipStream_t stream) {
+                         const void* resid, int ldres, const float* resid_keep, hipStream_t stream,
+                         const ConvArgs* bnsums) {
   UNETK_CHECK_ARG(in && wpacked && (out || head_out), "conv_fwd: null pointer");
   UNETK_CHECK_ARG((pooled == nullptr && head_out == nullptr) || (ks == 3 && resid == nullptr && out2 == nullptr),
                   "conv_fwd: pooled / head outputs need a 3x3 conv without residual or split");
@@ -1829,7 +1909,8 @@ static int conv_fwd_impl(const void* in, int ldin, const void* in2, int ldin2, i
                   "conv_fwd: pointers must be 16-byte aligned");
   UNETK_CHECK_ARG(resid == nullptr || (ldres % epp == 0 && ((uintptr_t)resid % 16) == 0),
                   "conv_fwd: residual misaligned");
-  ConvArgs a;
+  ConvArgs a = {};
+  if (bnsums != nullptr) a = *bnsums;        // (only the bs_* fields are set in it)
   a.in = in; a.w = wpacked; a.out = out; a.stats = stats;
   a.in2 = in2; a.ldin2 = ldin2; a.Ci1 = Ci1;
   a.out2 = out2; a.ldout2 = ldout2; a.split = out2 ? split : 0;
@@ -1845,6 +1926,25 @@ static int conv_fwd_impl(const void* in, int ldin, const void* in2, int ldin2, i
   return ks == 3 ? launch_conv<float, 3>(a, bn, stream) : launch_conv<float, 1>(a, bn, stream);
 }
 
+
+int unetk_conv_bwd_data_bnsums_supported(int Co, int bn, int dtype) {
+  static const bool off = getenv("UNETK_NO_CONV_BNSUMS") != nullptr;
+  return !off && dtype == UNETK_BF16 && (bn == 64 || bn == 96) && Co % 8 == 0;
+}
+
+int unetk_conv_bwd_data_bnsums(const void* dy, int lddy, const void* wpackedT, void* out, int B, int H, int W, int Ci,
+                               int Co, int bn, int dtype, const void* y, int ldy, const float* scale, const float* shift,
+                               const float* mean, const float* invstd, float* partials, hipStream_t stream) {
+  UNETK_CHECK_ARG(unetk_conv_bwd_data_bnsums_supported(Co, bn, dtype),
+                  "conv_bwd_data_bnsums: bfloat16 with a channel block of 64 or 96 only (Co=%d bn=%d dtype=%d)", Co, bn, dtype);
+  UNETK_CHECK_ARG(out && y && scale && shift && mean && invstd && partials, "conv_bwd_data_bnsums: null pointer");
+  UNETK_CHECK_ARG(ldy >= Co && ldy % 8 == 0 && ((uintptr_t)y % 16) == 0, "conv_bwd_data_bnsums: y misaligned or too narrow (ld %d)", ldy);
+  ConvArgs bs = {};
+  bs.bs_y = y; bs.ldbs = ldy; bs.bs_scale = scale; bs.bs_shift = shift; bs.bs_mean = mean; bs.bs_invstd = invstd;
+  bs.bs_partials = partials;
+  return conv_fwd_impl(dy, lddy, nullptr, 0, 0, wpackedT, out, Co, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, B, H,
+                       W, Ci, Co, 3, bn, dtype, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, stream, &bs);
+}
 
 int unetk_conv_fwd_split(const void* in, int ldin, const void* wpacked, void* out, int ldout, void* out2,
                          int ldout2, int split, int B, int H, int W, int Ci, int Co, int ks, int bn, int dtype,

@@ -1273,7 +1273,8 @@ static int bn_act_bwd_impl(const void* g, const float* g1_d, const float* g1_w, 
                            int W, int C, const float* scale, const float* shift, const float* mean,
                            const float* invstd, const float* keep, int relu, float* dgamma, float* dbeta,
                            int accumulate, float* partials, float* sums, int dtype, hipStream_t stream,
-                           const void* dpooled = nullptr, const unsigned char* argmax = nullptr, int ldg = 0) {
+                           const void* dpooled = nullptr, const unsigned char* argmax = nullptr, int ldg = 0,
+                           int nparts_given = 0) {
   UNETK_CHECK_ARG((g || (g1_d && g1_w)) && y && dy && scale && shift && mean && invstd && partials && sums,
                   "bn_act_bwd: null pointer");
   CHECK_DTYPE("bn_act_bwd", dtype);
@@ -1282,15 +1283,18 @@ static int bn_act_bwd_impl(const void* g, const float* g1_d, const float* g1_w, 
   UNETK_CHECK_ARG(C / E <= RED_THREADS, "bn_act_bwd: too many channels (%d)", C);
   const long npix = (long)B * H * W;
   UNETK_CHECK_ARG(npix < (1L << 31), "bn_act_bwd: too many pixels");
-  const int nblk = reduce_blocks(npix);
-  RedArgs r;
-  r.x = y; r.g = g; r.scale = scale; r.shift = shift; r.mean = mean; r.invstd = invstd; r.keep = keep;
-  r.partials = partials; r.npix = npix; r.hw = (long)H * W; r.C = C; r.ldx = C; r.ldg = dpooled ? ldg : C;
-  r.chunk = cdiv(npix, nblk); r.relu = relu; r.g1_d = g1_d; r.g1_w = g1_w;
-  r.dpooled = dpooled; r.argmax = argmax; r.H = H; r.W = W;
-  DISPATCH_T(dtype, hipLaunchKernelGGL((channel_reduce_kernel<T, 0>), dim3(nblk), dim3(RED_THREADS), 0,
-                                       stream, r));
-  UNETK_CHECK_LAUNCH();
+  // (nparts_given: the caller's `partials` already hold that many rows of the two sums, from the kernel that produced g)
+  const int nblk = nparts_given > 0 ? nparts_given : reduce_blocks(npix);
+  if (nparts_given <= 0) {
+    RedArgs r;
+    r.x = y; r.g = g; r.scale = scale; r.shift = shift; r.mean = mean; r.invstd = invstd; r.keep = keep;
+    r.partials = partials; r.npix = npix; r.hw = (long)H * W; r.C = C; r.ldx = C; r.ldg = dpooled ? ldg : C;
+    r.chunk = cdiv(npix, nblk); r.relu = relu; r.g1_d = g1_d; r.g1_w = g1_w;
+    r.dpooled = dpooled; r.argmax = argmax; r.H = H; r.W = W;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((channel_reduce_kernel<T, 0>), dim3(nblk), dim3(RED_THREADS), 0,
+                                         stream, r));
+    UNETK_CHECK_LAUNCH();
+  }
   // sums[0:C] = sum dz (= dbeta), sums[C:2C] = sum dz*xhat (= dgamma); the coefficients live behind
   // the two sum rows: sums must hold 6*C floats
   float* coef = sums + 2 * C;
@@ -1319,6 +1323,15 @@ int unetk_bn_act_bwd(const void* g, const void* y, void* dy, int B, int H, int W
   UNETK_CHECK_ARG(g != nullptr, "bn_act_bwd: null gradient");
   return bn_act_bwd_impl(g, nullptr, nullptr, y, dy, B, H, W, C, scale, shift, mean, invstd, keep, relu, dgamma, dbeta,
                          accumulate, partials, sums, dtype, stream);
+}
+
+int unetk_bn_act_bwd_presummed(const void* g, const void* y, void* dy, int B, int H, int W, int C, const float* scale,
+                               const float* shift, const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                               int accumulate, const float* partials, int nparts, float* sums, int dtype,
+                               hipStream_t stream) {
+  UNETK_CHECK_ARG(g != nullptr && nparts > 0, "bn_act_bwd_presummed: null gradient or no partial sums");
+  return bn_act_bwd_impl(g, nullptr, nullptr, y, dy, B, H, W, C, scale, shift, mean, invstd, nullptr, 1, dgamma, dbeta,
+                         accumulate, const_cast<float*>(partials), sums, dtype, stream, nullptr, nullptr, 0, nparts);
 }
 
 int unetk_bn_act_bwd_rank1(const float* gpix, const float* gchan, const void* y, void* dy, int B, int H, int W, int C,

@@ -279,6 +279,28 @@ def conv_fwd(x: torch.Tensor, pw: PackedConv, Ci: Optional[int] = None, Co: Opti
     return out, stats
 
 
+def conv_bwd_data_bnsums_supported(pw: PackedConv, dt) -> bool:
+    return pw.ks == 3 and bool(_lib.load().unetk_conv_bwd_data_bnsums_supported(pad_channels(pw.Co, dt), pw.bn,
+                                                                                dtype_code(dt)))
+
+
+def conv_bwd_data_bnsums(dy: torch.Tensor, pwT: PackedConv, y, scale, shift, mean, invstd):
+    """g = data gradient of a 3x3 conv (``pwT``: its weights packed transposed), the gradient of relu(y*scale+shift);
+    returns (g, partials): the per-tile sums that ``bn_act_bwd(..., presummed=partials)`` takes instead of reducing
+    g and y itself."""
+    B, H, W, _ = dy.shape
+    dt = dy.dtype
+    Ci, Co = min(dy.shape[-1], pad_channels(pwT.Ci, dt)), pad_channels(pwT.Co, dt)
+    if y.shape != (B, H, W, Co) or y.dtype != dt or y.stride(3) != 1 or y.stride(1) != W * y.stride(2):
+        raise ValueError("conv_bwd_data_bnsums: y does not match the gradient being produced")
+    out = torch.empty((B, H, W, Co), dtype=dt, device=dy.device)
+    nt = _lib.load().unetk_conv_num_tiles(B, H, W, 3)
+    partials = torch.empty((nt, 2, Co), dtype=torch.float32, device=dy.device)
+    call("unetk_conv_bwd_data_bnsums", ptr(dy), dy.stride(2), ptr(pwT.data), ptr(out), B, H, W, Ci, Co, pwT.bn,
+         dtype_code(dt), ptr(y), y.stride(2), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(partials), stream())
+    return out, partials
+
+
 def linear_supported(x: torch.Tensor, pw: PackedConv) -> bool:
     """Whether the token-linear GEMM kernel takes this product (bfloat16, K a multiple of 32, N a multiple of the
     packed channel block); everything else goes through the 1x1 form of the convolution kernel."""
@@ -472,20 +494,27 @@ class PooledGrad:
 
 
 def bn_act_bwd(g, y, scale, shift, mean, invstd, keep=None, relu=True, dgamma=None, dbeta=None,
-               accumulate=False):
+               accumulate=False, presummed=None):
     """Returns (dy, dgamma, dbeta).  ``g`` is the gradient of the activation, or a pair (gpix (B,H,W) fp32,
     gchan (C,) fp32) standing for the rank-one gradient gpix[b,y,x] * gchan[c] that is never materialised, or a
     PooledGrad: the gradient through a 2x2 max-pool plus a skip gradient, formed inside the passes."""
     B, H, W, C = y.shape
     dev = y.device
     dy = torch.empty_like(y)
-    nparts = _lib.load().unetk_reduce_num_partials(B * H * W)
-    partials = torch.empty((nparts, 2, C), dtype=torch.float32, device=dev)
     sums = torch.empty((6, C), dtype=torch.float32, device=dev)
     if dgamma is None:
         dgamma = torch.empty(C, dtype=torch.float32, device=dev)
         dbeta = torch.empty(C, dtype=torch.float32, device=dev)
         accumulate = False
+    if presummed is not None:       # (rows of the two sums left by conv_bwd_data_bnsums, which produced g)
+        if keep is not None or not relu or presummed.shape[1:] != (2, C) or not presummed.is_contiguous():
+            raise ValueError("bn_act_bwd: presummed partials go with ReLU, no keep factors and shape (n, 2, C)")
+        call("unetk_bn_act_bwd_presummed", ptr(g), ptr(y), ptr(dy), B, H, W, C, ptr(scale), ptr(shift), ptr(mean),
+             ptr(invstd), ptr(dgamma), ptr(dbeta), 1 if accumulate else 0, ptr(presummed), presummed.shape[0],
+             ptr(sums), dtype_code(y.dtype), stream())
+        return dy, dgamma, dbeta
+    nparts = _lib.load().unetk_reduce_num_partials(B * H * W)
+    partials = torch.empty((nparts, 2, C), dtype=torch.float32, device=dev)
     if isinstance(g, PooledGrad):
         assert g.dpooled.shape == (B, H // 2, W // 2, C) and g.dskip.shape == (B, H, W, C) and g.dskip.stride(3) == 1
         assert g.dpooled.is_contiguous() and g.argmax.is_contiguous() and g.dskip.stride(1) == W * g.dskip.stride(2)

@@ -105,6 +105,10 @@ class OptimizedUNet(nn.Module):
 OVERLAP_WGRAD = os.environ.get("UNETK_OVERLAP_WGRAD", "0") != "0"
 # the gradient through an encoder's max-pool (+ its skip gradient) formed inside the BatchNorm-backward passes
 # instead of stored by a pass of its own (0: the separate pass, for A/B timing; same bits either way)
+FUSE_BN_SUMS = os.environ.get("UNETK_FUSE_BN_SUMS", "1") != "0"
+# ... for activations up to this many bytes: a larger one is reduced faster by the separate pass, which finds much of
+# the gradient just written still in the last-level cache, than by a conv epilogue that has to fetch y again
+BN_SUMS_MAX_BYTES = int(os.environ.get("UNETK_BN_SUMS_MAX_BYTES", str(64 << 20)))
 FUSE_POOL_BWD = os.environ.get("UNETK_FUSE_POOL_BWD", "1") != "0"
 _SIDE_STREAMS = {}
 
@@ -325,20 +329,30 @@ class _UNetTrainFn(torch.autograd.Function):
         def block_bwd(name, g, need_dx=True, split=0):
             seq = getattr(model, name)
             units, _, keep = saved[name]
+            presummed = None
             for u in (1, 0):
                 ci, bi = ((0, 1), (3, 4))[u]
                 t_in, y, mean, invstd, sc, sh = units[u]
                 dy, dgamma, dbeta = ops.bn_act_bwd(g, y, sc, sh, mean, invstd,
-                                                   keep if u == 1 else None, relu=True)
+                                                   keep if u == 1 else None, relu=True, presummed=presummed)
+                presummed = None
                 grads[f"{name}.{bi}.weight"], grads[f"{name}.{bi}.bias"] = dgamma, dbeta
                 conv = seq[ci]
                 def wgrad():
                     return ops.conv_wgrad(t_in, dy, conv.in_channels, conv.out_channels, 3)
 
                 def dgrad():
+                    nonlocal presummed
                     if not (u == 1 or need_dx):
                         return None
                     pw = pkT[(name, ci)]
+                    if (u == 1 and FUSE_BN_SUMS and units[0][1].numel() * units[0][1].element_size() <= BN_SUMS_MAX_BYTES
+                            and ops.conv_bwd_data_bnsums_supported(pw, dt)):
+                        # the gradient this conv produces goes straight into the first unit's BatchNorm backward:
+                        # the conv leaves that pass's two sums beside it
+                        _, y0, mean0, invstd0, sc0, sh0 = units[0]
+                        gg, presummed = ops.conv_bwd_data_bnsums(dy, pw, y0, sc0, sh0, mean0, invstd0)
+                        return gg
                     # the first conv of a decoder block read cat([up, skip]): its data gradient comes
                     # out as two dense tensors (when the boundary falls on a channel block)
                     sp = split if (u == 0 and split and split % pw.bn == 0) else 0
