@@ -138,12 +138,27 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
   // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  The (ci chunk, co
   // block) workgroups of one pixel-tile list share every dy tile and halo, so they are given
   // linear ids that differ by multiples of 8: same XCD, dispatched back to back, and the
-  // re-reads hit that XCD's L2 instead of HBM.
+  // re-reads hit that XCD's L2 instead of each of the eight L2s fetching the tile for itself.
+  // XCD x (workgroups lin = x, x+8, ...) walks the x-th contiguous eighth of the list ordered (pixel split, chunk,
+  // block), the pixel splits in the order 0, 8, 16, ..., 1, 9, 17, ...: with a multiple of 8 splits XCD x has the
+  // splits x, x+8, ..., so the tiles in work across the chip at one time are neighbours in memory; with any other
+  // count a split may straddle two XCDs.  The grid is padded to a multiple of 8; the surplus workgroups leave.
   const int gxy = a.gx * a.gy;
   const int lin = blockIdx.x;
-  const bool xcd_map = (a.nsplit & 7) == 0;
-  const int cxy = xcd_map ? (lin >> 3) % gxy : lin % gxy;
-  const int bz = xcd_map ? ((lin >> 3) / gxy) * 8 + (lin & 7) : lin / gxy;
+  const int pos = (lin & 7) * (int)(gridDim.x >> 3) + (lin >> 3);
+  if (pos >= gxy * a.nsplit) return;
+  const int cxy = pos % gxy;
+  int bz;
+  {
+    const int sidx = pos / gxy, nfull = a.nsplit >> 3, rem = a.nsplit & 7;
+    const int head = rem * (nfull + 1);          // splits in the residue classes that hold one more
+    if (sidx < head) {
+      bz = sidx / (nfull + 1) + 8 * (sidx % (nfull + 1));
+    } else {
+      const int s2 = sidx - head;                // (nfull > 0 here: head == nsplit otherwise)
+      bz = rem + s2 / nfull + 8 * (s2 % nfull);
+    }
+  }
   const int ci0 = (cxy % a.gx) * KCI;
   const int co0 = (cxy / a.gx) * BM;
   // the input may be the channel concatenation [in | in2] of two tensors (never stored as one): a
@@ -922,7 +937,6 @@ WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int dtype, int ks, boo
     const long rounds = (wgs + 255) / 256;
     double score = (double)wgs / (256.0 * rounds) / (1.0 + c * t_slab / t_mul);
     if (rounds < 2) score *= 0.8;
-    if ((c & 7) == 0) score *= 1.15;       // enables the XCD-aware workgroup order (shared tiles hit one L2)
     if (score > best) {
       best = score;
       s = c;
@@ -945,7 +959,7 @@ inline void refold_1x1(int& B, int& H, int& W, int ks) {
 
 template <typename T, int KS>
 int launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t stream) {
-  dim3 grid((unsigned)(a.gx * a.gy * p.nsplit));
+  dim3 grid((unsigned)(8 * cdiv(a.gx * a.gy * p.nsplit, 8)));
 #define WG_CASE(MT_, TW_, NWN_)                                                                        \
   if (p.mt == MT_ && p.tw == TW_ && p.nwn == NWN_) {                                                   \
     hipLaunchKernelGGL((conv_wgrad_kernel<T, MT_, TW_, KS, NWN_>), grid, dim3(512), 0, stream, a);     \
