@@ -346,6 +346,9 @@ class _Ctx:
 # chain leaves idle at every kernel's ramp-up and tail.  A data-parallel gradient sink receives each of those
 # gradients on that second stream (unet_amd.dist.GradReducer orders its buckets' collectives behind both streams).
 OVERLAP_WGRAD = os.environ.get("UNETK_SWIN_OVERLAP_WGRAD", "1") != "0"
+# the decoder's data-gradient convs leave the BatchNorm-backward sums of the unit in front (see UNet's backward)
+FUSE_BN_SUMS = os.environ.get("UNETK_FUSE_BN_SUMS", "1") != "0"
+BN_SUMS_MAX_BYTES = int(os.environ.get("UNETK_BN_SUMS_MAX_BYTES", str(64 << 20)))
 DEFER_LN_SUMS = os.environ.get("UNETK_SWIN_DEFER_LN_SUMS", "1") != "0"     # LayerNorm dgamma / dbeta sums: one launch at the end of the backward
 CONVT_BWD_GATHER = os.environ.get("UNETK_SWIN_CONVT_BWD_GATHER", "1") != "0"   # ConvTranspose data gradient reads the gradient image in place
 # The MLP branch of the 96- and 192-channel blocks as ONE launch (LayerNorm, fc1, GELU, fc2, residual): the hidden
@@ -575,17 +578,25 @@ def _conv_bn_relu_fwd(conv, bn, t, cx, training, save, tag):
     return a
 
 
-def _conv_bn_relu_bwd(conv, bn, tag, ctx, g, cx, grads, need_dx=True):
+def _conv_bn_relu_bwd(conv, bn, tag, ctx, g, cx, grads, need_dx=True, feeds=None, presummed=None):
+    """``feeds``: the saved tensors of the Conv-BN-ReLU unit whose activation this conv read, when the gradient goes
+    straight into that unit's BatchNorm backward: the data-gradient conv then leaves that pass's two sums, returned as
+    the second value (None otherwise) and handed back in as ``presummed`` with the next call."""
     t, y, mean, invstd, sc, sh = ctx
-    dy, dgamma, dbeta = ops.bn_act_bwd(g, y, sc, sh, mean, invstd, None, relu=True)
+    dy, dgamma, dbeta = ops.bn_act_bwd(g, y, sc, sh, mean, invstd, None, relu=True, presummed=presummed)
     cname, bname = tag
     grads[bname + ".weight"], grads[bname + ".bias"] = dgamma, dbeta
     grads[cname + ".weight"] = _on_side(cx, lambda: ops.conv_wgrad(t, dy, conv.in_channels, conv.out_channels, 3), t, dy)
     if conv.bias is not None:
         grads[cname + ".bias"] = torch.zeros_like(conv.bias)      # exactly 0 in front of BatchNorm
-    if need_dx:
-        return ops.conv_fwd(dy, cx.packed(conv.weight, transpose=True))[0]
-    return None
+    if not need_dx:
+        return None, None
+    pwT = cx.packed(conv.weight, transpose=True)
+    if feeds is not None and FUSE_BN_SUMS and feeds[1].shape == t.shape and \
+            t.numel() * t.element_size() <= BN_SUMS_MAX_BYTES and ops.conv_bwd_data_bnsums_supported(pwT, cx.dt):
+        _, y0, mean0, invstd0, sc0, sh0 = feeds
+        return ops.conv_bwd_data_bnsums(dy, pwT, y0, sc0, sh0, mean0, invstd0)
+    return ops.conv_fwd(dy, pwT)[0], None
 
 
 def _decoder_fwd(dec, pre, x, skip, cx, training, save):
@@ -731,6 +742,7 @@ class _SwinTrainFn(torch.autograd.Function):
         g = None
         pending_skip = None
         g_scaled = None                  # g times the next block's DropPath factors, when its producer wrote it
+        presummed = None                 # BatchNorm-backward sums of the next unit, when g's producer left them
         for ri in range(len(save) - 1, -1, -1):
             rec = save[ri]
             kind = rec[0]
@@ -744,7 +756,11 @@ class _SwinTrainFn(torch.autograd.Function):
                 grads["final_conv.3.weight"], grads["final_conv.3.bias"] = dw, db
             elif kind == "cbr":
                 _, conv, bn, tag, c = rec
-                g = _conv_bn_relu_bwd(conv, bn, tag, c, g, cx, grads)
+                below = ri - 1
+                while save[below][0] == "dec_tail":
+                    below -= 1
+                feeds = save[below][4] if save[below][0] == "cbr" else None
+                g, presummed = _conv_bn_relu_bwd(conv, bn, tag, c, g, cx, grads, feeds=feeds, presummed=presummed)
             elif kind == "dec_tail":
                 pass
             elif kind == "dec_head":
