@@ -249,7 +249,7 @@ def test_bn_bwd_with_the_pool_gradient_formed_inside(dt, shape):
 
 
 @pytest.mark.parametrize("shape", [(2, 32, 32, 96, 96), (3, 19, 23, 64, 128), (1, 16, 16, 192, 96), (2, 7, 40, 96, 64),
-                                   (5, 33, 17, 288, 192)])
+                                   (5, 33, 17, 288, 192), (2, 20, 21, 72, 40), (1, 5, 3, 136, 96)])
 def test_bn_bwd_sums_from_the_data_gradient_conv(shape):
     """The data-gradient conv that leaves BatchNorm-backward's two sums beside its output
     (unetk_conv_bwd_data_bnsums + unetk_bn_act_bwd_presummed): the gradient itself has the same bits as the plain
