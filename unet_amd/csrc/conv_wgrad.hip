@@ -159,8 +159,11 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
       bz = rem + s2 / nfull + 8 * (s2 % nfull);
     }
   }
-  const int ci0 = (cxy % a.gx) * KCI;
-  const int co0 = (cxy / a.gx) * BM;
+  // (the shorter of the two axes runs fastest: the ~32 workgroups an XCD has in flight then form the squarest patch
+  // of the (chunk, block) plane, i.e. share the fewest distinct dy tiles and halos)
+  const bool co_fast = a.gy < a.gx;
+  const int ci0 = (co_fast ? cxy / a.gy : cxy % a.gx) * KCI;
+  const int co0 = (co_fast ? cxy % a.gy : cxy / a.gx) * BM;
   // the input may be the channel concatenation [in | in2] of two tensors (never stored as one): a
   // workgroup's chunk lies in one of them (Ci1 is a multiple of the chunk)
   const T* in = reinterpret_cast<const T*>(a.in);
