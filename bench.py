@@ -193,6 +193,7 @@ class ConvTimer:
         self.ops = ops
         self.orig = ops.conv_fwd
         self.orig_cat = ops.conv_fwd_cat
+        self.orig_sums = ops.conv_bwd_data_bnsums
         self.records = []
 
     def __enter__(self):
@@ -222,13 +223,28 @@ class ConvTimer:
                                 bytes=float(npix * (pw.Ci + pw.Co) * esz + pw.data.numel() * esz)))
             return r
 
+        orig_sums = self.orig_sums
+
+        def timed_conv_sums(dy, pw, *a, **k):         # the data-gradient launches that also leave BatchNorm-backward sums
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig_sums(dy, pw, *a, **k)
+            e1.record()
+            npix = dy.numel() // dy.shape[-1]
+            esz = dy.element_size()
+            records.append(dict(e0=e0, e1=e1, flops=2.0 * npix * pw.Co * pw.Ci * pw.ks * pw.ks, bn=pw.bn, ks=pw.ks,
+                                bytes=float(npix * (pw.Ci + 2 * pw.Co) * esz + pw.data.numel() * esz)))
+            return r
+
         self.ops.conv_fwd = timed_conv
         self.ops.conv_fwd_cat = timed_conv_cat
+        self.ops.conv_bwd_data_bnsums = timed_conv_sums
         return self
 
     def __exit__(self, *exc):
         self.ops.conv_fwd = self.orig
         self.ops.conv_fwd_cat = self.orig_cat
+        self.ops.conv_bwd_data_bnsums = self.orig_sums
 
     def family(self, pred):
         rows = [(r["e0"].elapsed_time(r["e1"]), r["flops"], r["bytes"]) for r in self.records if pred(r)]
