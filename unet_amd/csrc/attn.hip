@@ -115,6 +115,10 @@ __device__ __forceinline__ void issue_item(const AttnArgs& g, const Item& it, ch
   }
 }
 
+// LDS hand-over between the lanes of ONE wave (the backward's workgroup): the wave's LDS operations execute in order,
+// so draining them is all it takes.  (__syncthreads() would also wait for the item's global stores to be acknowledged.)
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 // fragment of rows 16*tile .. +15 of a staged operand (A: row = lane&15; B: column = lane&15), k = head dim
 __device__ __forceinline__ bf16x8 frag_rows(const char* op, int tile, int lane) {
   const int l15 = lane & 15, q4 = lane >> 4;
@@ -300,8 +304,12 @@ __global__ __launch_bounds__(64) void attn_fwd_bf16_kernel(AttnArgs g) {
 // --------------------------------------------------------------------------------------- backward
 // Recomputes P, then dV = P^T dO, dP = dO V^T, dS = P*(dP - rowsum(dP*P)), dQ = scale*dS K,
 // dK = scale*dS^T Q and the item's row of bias-table gradient partials.
-__global__ __launch_bounds__(64) void attn_bwd_bf16_kernel(AttnArgs g) {
-  __shared__ __attribute__((aligned(1024))) char buf[2][4 * OPB];
+// One wave a workgroup and ONE operand buffer (19 KB of LDS: eight workgroups a CU, two waves a SIMD): the next item's
+// DMA goes out when this item is through with the buffer, and the other wave of the SIMD works meanwhile.  (A double
+// buffer - 35 KB, one wave a SIMD - hid the DMA but nothing else: every exp, shuffle and LDS round trip of the single
+// wave left the SIMD idle.)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_bf16_kernel(AttnArgs g) {
+  __shared__ __attribute__((aligned(1024))) char buf[4 * OPB];
   __shared__ float tbl[2][256];
   __shared__ __attribute__((aligned(16))) float stat[2][64];      // per query: log-sum-exp, sum_key dP*P
   const int lane = threadIdx.x;
@@ -316,26 +324,23 @@ __global__ __launch_bounds__(64) void attn_bwd_bf16_kernel(AttnArgs g) {
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
 
   Item cur = decode_item(g, i0);
-  issue_item<true>(g, cur, buf[0], lane);
-  for (int i = lane; i < 225; i += 64) tbl[0][i] = g.table[i * g.heads + cur.head];
+  // the head's column of the bias table travels with the item: loaded into registers in front of the item's DMA
+  // (loads complete in order: behind the DMA it would have to wait for all of it), written to LDS once both are in
+  float tnext[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) tnext[k] = (lane + 64 * k < 225) ? g.table[(lane + 64 * k) * g.heads + cur.head] : 0.f;
+  issue_item<true>(g, cur, buf, lane);
 
 #pragma unroll 1
   for (int it = i0; it < i1; ++it) {
     const int c = (it - i0) & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const bool more = it + 1 < i1;
-    Item nxt = cur;
-    float tnext[4] = {0.f, 0.f, 0.f, 0.f};
-    if (more) {
-      nxt = decode_item(g, it + 1);
-      issue_item<true>(g, nxt, buf[c ^ 1], lane);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int idx = lane + 64 * k;
-        if (idx < 225) tnext[k] = g.table[idx * g.heads + nxt.head];
-      }
-    }
-    char* Q = buf[c];
+    for (int k = 0; k < 4; ++k)
+      if (lane + 64 * k < 225) tbl[c][lane + 64 * k] = tnext[k];
+    wave_lds_sync();
+    const bool more = it + 1 < i1;
+    char* Q = buf;
     char* K = Q + OPB;
     char* V = Q + 2 * OPB;
     char* D = Q + 3 * OPB;
@@ -351,17 +356,11 @@ __global__ __launch_bounds__(64) void attn_bwd_bf16_kernel(AttnArgs g) {
       df[t] = frag_rows(D, t, lane);
     }
 
-    // ---- orientation 1: rows = keys.  P^T, dP^T -> log-sum-exp, delta, dS^T (B operand of dQ)
+    // ---- orientation 1: rows = keys.  P^T, dP^T -> log-sum-exp, delta, dS^T (B operand of dQ).  One query tile (a
+    // column block of S^T) at a time: its softmax needs nothing of the others, and 8 accumulator tiles are live
+    // instead of 32 (the kernel then fits two waves a SIMD).
     bf16x8 dsT[4][2];
     {
-      f32x4 s[4][4], dp[4][4];
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          s[mt][nt] = mfma16(kf[mt], qf[nt], zero4);
-          dp[mt][nt] = mfma16(vf[mt], df[nt], zero4);
-        }
       float bias[7][4];
 #pragma unroll
       for (int d = 0; d < 7; ++d)
@@ -369,13 +368,19 @@ __global__ __launch_bounds__(64) void attn_bwd_bf16_kernel(AttnArgs g) {
         for (int r = 0; r < 4; ++r) bias[d][r] = tb[baseT + 30 * (d - 3) - r];
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          s[mt] = mfma16(kf[mt], qf[nt], zero4);
+          dp[mt] = mfma16(vf[mt], df[nt], zero4);
+        }
         float mx = -INFINITY;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float v = fmaf(s[mt][nt][r], g.scale, bias[nt - mt + 3][r]) + (((mt >= 2) != (nt >= 2)) ? mk.xy : mk.x);
-            s[mt][nt][r] = v;
+            const float v = fmaf(s[mt][r], g.scale, bias[nt - mt + 3][r]) + (((mt >= 2) != (nt >= 2)) ? mk.xy : mk.x);
+            s[mt][r] = v;
             mx = fmaxf(mx, v);
           }
         mx = xor16_32_max(mx);
@@ -384,8 +389,8 @@ __global__ __launch_bounds__(64) void attn_bwd_bf16_kernel(AttnArgs g) {
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float e = __expf(s[mt][nt][r] - mx);
-            s[mt][nt][r] = e;
+            const float e = __expf(s[mt][r] - mx);
+            s[mt][r] = e;
             sum += e;
           }
         sum = xor16_32_sum(sum);
@@ -395,9 +400,9 @@ __global__ __launch_bounds__(64) void attn_bwd_bf16_kernel(AttnArgs g) {
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float p = s[mt][nt][r] * inv;
-            s[mt][nt][r] = p;
-            dl += p * dp[mt][nt][r];
+            const float p = s[mt][r] * inv;
+            s[mt][r] = p;
+            dl += p * dp[mt][r];
           }
         dl = xor16_32_sum(dl);
         if (pg == 0) {
@@ -407,52 +412,48 @@ __global__ __launch_bounds__(64) void attn_bwd_bf16_kernel(AttnArgs g) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s[mt][nt][r] *= dp[mt][nt][r] - dl;
-        dsT[nt][0] = pack8(s[0][nt], s[1][nt]);
-        dsT[nt][1] = pack8(s[2][nt], s[3][nt]);
+          for (int r = 0; r < 4; ++r) s[mt][r] *= dp[mt][r] - dl;
+        dsT[nt][0] = pack8(s[0], s[1]);
+        dsT[nt][1] = pack8(s[2], s[3]);
       }
     }
     __syncthreads();      // (one wave: orders the statistics' LDS round trip)
 
-    // ---- orientation 2: rows = queries.  P and dS as the B operands of dV and dK
+    // ---- orientation 2: rows = queries.  P and dS as the B operands of dV and dK, one key tile at a time
     bf16x8 pB[4][2], dsB[4][2];
     {
-      f32x4 s[4][4], dp[4][4];
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          s[mt][nt] = mfma16(qf[mt], kf[nt], zero4);
-          dp[mt][nt] = mfma16(df[mt], vf[nt], zero4);
-        }
       float bias[7][4];
 #pragma unroll
       for (int d = 0; d < 7; ++d)
 #pragma unroll
         for (int r = 0; r < 4; ++r) bias[d][r] = tb[baseS + 30 * (d - 3) + r];
-      f32x4 lse[4], dl[4];
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        lse[mt] = *reinterpret_cast<const f32x4*>(&stat[0][16 * mt + 4 * pg]);
-        dl[mt] = *reinterpret_cast<const f32x4*>(&stat[1][16 * mt + 4 * pg]);
-      }
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float v = fmaf(s[mt][nt][r], g.scale, bias[mt - nt + 3][r]) + (((mt >= 2) != (nt >= 2)) ? mk.xy : mk.x);
-            const float p = __expf(v - lse[mt][r]);
-            s[mt][nt][r] = p;
-            dp[mt][nt][r] = p * (dp[mt][nt][r] - dl[mt][r]);
-          }
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        pB[nt][0] = pack8(s[0][nt], s[1][nt]);
-        pB[nt][1] = pack8(s[2][nt], s[3][nt]);
-        dsB[nt][0] = pack8(dp[0][nt], dp[1][nt]);
-        dsB[nt][1] = pack8(dp[2][nt], dp[3][nt]);
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          s[mt] = mfma16(qf[mt], kf[nt], zero4);
+          dp[mt] = mfma16(df[mt], vf[nt], zero4);
+        }
+        // (the queries' statistics are read again for every key tile - 32 registers that the kernel does not have
+        // at two waves a SIMD; the fence keeps the compiler from hoisting the reads out of the loop)
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const f32x4 lse = *reinterpret_cast<const f32x4*>(&stat[0][16 * mt + 4 * pg]);
+          const f32x4 dl = *reinterpret_cast<const f32x4*>(&stat[1][16 * mt + 4 * pg]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = fmaf(s[mt][r], g.scale, bias[mt - nt + 3][r]) + (((mt >= 2) != (nt >= 2)) ? mk.xy : mk.x);
+            const float p = __expf(v - lse[r]);
+            s[mt][r] = p;
+            dp[mt][r] = p * (dp[mt][r] - dl[r]);
+          }
+        }
+        pB[nt][0] = pack8(s[0], s[1]);
+        pB[nt][1] = pack8(s[2], s[3]);
+        dsB[nt][0] = pack8(dp[0], dp[1]);
+        dsB[nt][1] = pack8(dp[2], dp[3]);
       }
     }
 
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(64) void attn_bwd_bf16_kernel(AttnArgs g) {
           *reinterpret_cast<u32x2*>(tile + qi * 128 + s_hi * 16 + 8 * (pg & 1)) = u32x2{w[2], w[3]};
         }
       }
-      __syncthreads();
+      wave_lds_sync();
       // lane (yi, yj): the 8x8 block of queries 8yi.. and keys 8yj..; its 15 diagonals xi - xj
       const int yi = lane >> 3, yj = lane & 7;
       float diag[2 * AWS - 1];
@@ -521,7 +522,7 @@ __global__ __launch_bounds__(64) void attn_bwd_bf16_kernel(AttnArgs g) {
       float* blk = reinterpret_cast<float*>(Q);                  // [yi][yj][16]; Q is dead
 #pragma unroll
       for (int k = 0; k < 2 * AWS - 1; ++k) blk[lane * 16 + k] = diag[k];
-      __syncthreads();
+      wave_lds_sync();
       float* dst = g.dtable_partials + (long)it * 225;
       for (int bin = lane; bin < 225; bin += 64) {
         const int dy = bin / 15 - 7, dxk = bin % 15;
@@ -538,12 +539,17 @@ __global__ __launch_bounds__(64) void attn_bwd_bf16_kernel(AttnArgs g) {
     }
 
     if (more) {
+      wave_lds_sync();      // every read of the operand buffer (and of the scratch tiles laid over it) is done
+      cur = decode_item(g, it + 1);
+      // (the lane index made opaque: what the DMA addresses derive from it is then computed here, a few operations,
+      // instead of being kept - spilled - across the item; a spill reload between two DMA pieces waits for vmcnt(0),
+      // i.e. for every piece before it)
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int idx = lane + 64 * k;
-        if (idx < 225) tbl[c ^ 1][idx] = tnext[k];
-      }
-      cur = nxt;
+      for (int k = 0; k < 4; ++k)
+        tnext[k] = (lane_o + 64 * k < 225) ? g.table[(lane_o + 64 * k) * g.heads + cur.head] : 0.f;
+      issue_item<true>(g, cur, buf, lane_o);
     }
   }
 }
@@ -587,7 +593,7 @@ int attn_bf16_fwd(const AttnLaunch& a, hipStream_t stream) {
 
 int attn_bf16_bwd(const AttnLaunch& a, hipStream_t stream) {
   const AttnArgs g = to_args(a);
-  const int slots = cu_count() * 4;            // 4 x 35 KB of LDS per CU
+  const int slots = cu_count() * 8;            // 8 x 19 KB of LDS per CU
   const int grid = g.nitems < slots ? g.nitems : slots;
   hipLaunchKernelGGL(attn_bwd_bf16_kernel, dim3((unsigned)grid), dim3(64), 0, stream, g);
   UNETK_CHECK_LAUNCH();
