@@ -3,7 +3,9 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from unet_amd import ops
+from unet_amd import ops, _lib
+if os.environ.get("UNETK_AB_LIB"):      # A/B a kernel variant built to another file
+    _lib.LIB_PATH = os.path.abspath(os.environ["UNETK_AB_LIB"])
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 

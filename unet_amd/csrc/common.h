@@ -62,6 +62,20 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
+// "At most VM of this wave's vector-memory operations still outstanding" (and, with LGKM0, none of its LDS / scalar
+// ones), then the workgroup barrier.  The wait goes through the s_waitcnt BUILTIN: the compiler's own wait insertion
+// reads it and knows which LDS-DMA transfers have landed.  Written as inline asm the wait is opaque to it, and it puts
+// a vmcnt(0) of its own in front of the first LDS read of a buffer it believes a DMA may still be filling - which
+// drains the newer transfers that were meant to stay in flight.  (gfx9 encoding: vmcnt in bits 3:0 and 15:14,
+// expcnt 6:4, lgkmcnt 11:8.)
+template <int VM, bool LGKM0>
+__device__ __forceinline__ void wait_vm_then_barrier() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_s_waitcnt((VM & 15) | (7 << 4) | ((LGKM0 ? 0 : 15) << 8) | ((VM >> 4) << 14));
+  asm volatile("s_barrier" ::: "memory");
+#endif
+}
+
 // Error plumbing shared by the C-ABI entry points.
 void unetk_set_error(const char* fmt, ...);
 #define UNETK_CHECK_ARG(cond, ...)                       \

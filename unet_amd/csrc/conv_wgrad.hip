@@ -400,8 +400,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
     // but the NPW newest" whenever tile j+1 has been issued.  After the barrier tile j is complete
     // and every wave is done with tile j-1, whose stage the next issue overwrites.
     auto sync_tile = [&](bool newer_in_flight) {
-      if (newer_in_flight) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NPW) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      if (newer_in_flight) wait_vm_then_barrier<NPW, false>();      // (the builtin form: see common.h)
+      else wait_vm_then_barrier<0, false>();
     };
     if (n > 0) issue_tile(tile_at(0), buf0);
     if (n > 1) issue_tile(tile_at(1), buf1);

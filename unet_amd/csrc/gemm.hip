@@ -356,7 +356,17 @@ __global__ __launch_bounds__(64 * WM * WN) void lin_wgrad_kernel(WgArgs a) {
   constexpr int DPIECES = TT * RBD / 1024, XPIECES = TT * RBX / 1024;
   constexpr int DBYTES = TT * RBD, STAGE = TT * (RBD + RBX);
   constexpr int AHEAD = NSTAGE - 1;                      // stages in flight behind the one being multiplied
-  __shared__ __attribute__((aligned(1024))) char lds[NSTAGE * STAGE];
+  // One LDS object per stage.  In the steady-state loop (unrolled six times: three slots x two register sets) every
+  // stage is picked by a compile-time index and the waits go through the s_waitcnt builtin, so the compiler's own wait
+  // insertion knows (a) that the DMA filling one stage cannot alias the transposing reads of another and (b) which
+  // DMAs have landed.  With one array, a run-time stage and waits in inline asm it put a vmcnt(0) in front of the
+  // first read of every stage (the builtin read carries no address information): the ring never had more than
+  // the stage being read in flight.  The last stages of a range still take that form.
+  static_assert(NSTAGE == 3, "three stages: see the loop");
+  __shared__ __attribute__((aligned(1024))) char lds0[STAGE];
+  __shared__ __attribute__((aligned(1024))) char lds1[STAGE];
+  __shared__ __attribute__((aligned(1024))) char lds2[STAGE];
+  auto slot_ptr = [&](int slot) __attribute__((always_inline)) -> char* { return slot == 0 ? lds0 : (slot == 1 ? lds1 : lds2); };
   static_assert(RBD % 256 == 0 && RBX % 256 == 0, "rows are whole bank rows");
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -420,8 +430,7 @@ __global__ __launch_bounds__(64 * WM * WN) void lin_wgrad_kernel(WgArgs a) {
     xptr[k] = ok ? a.x + (long)t_begin * a.ldx + x_off[k] : zero;
     xstep[k] = ok ? (long)TT * a.ldx : 0;
   }
-  auto issue_full = [&](int slot) __attribute__((always_inline)) {
-    char* dst = lds + slot * STAGE;
+  auto issue_full = [&](char* dst) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < DPW; ++k) {
       glds16g(dptr[k], dst + (wave + NW * k) * 1024);
@@ -434,11 +443,11 @@ __global__ __launch_bounds__(64 * WM * WN) void lin_wgrad_kernel(WgArgs a) {
     }
   };
   auto issue_any = [&](int st, int slot) __attribute__((always_inline)) {
+    char* dst = slot_ptr(slot);
     if (st < nfull) {          // (uniform)
-      issue_full(slot);
+      issue_full(dst);
       return;
     }
-    char* dst = lds + slot * STAGE;
     const int t0 = t_begin + st * TT;
     const bf16* dbase = a.dy + (long)t0 * a.lddy;
     const bf16* xbase = a.x + (long)t0 * a.ldx;
@@ -482,9 +491,8 @@ __global__ __launch_bounds__(64 * WM * WN) void lin_wgrad_kernel(WgArgs a) {
   // straight-line code with a compile-time wait count; the last stages of a range take the general form.
   typedef __attribute__((ext_vector_type(8))) short short8v;
   bf16x8 af[2][4], bfr[2][4];
-  auto load_frags = [&](auto bufc, int slot) __attribute__((always_inline)) {
+  auto load_frags = [&](auto bufc, const char* base) __attribute__((always_inline)) {
     constexpr int BUF = decltype(bufc)::value;
-    const char* base = lds + slot * STAGE;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, base + a_addr[m]));
@@ -517,20 +525,20 @@ __global__ __launch_bounds__(64 * WM * WN) void lin_wgrad_kernel(WgArgs a) {
   };
   auto next3 = [](int st) { return st == 2 ? 0 : st + 1; };
   int sr = 1, si = 0;          // slot of stage st+1 (read next), slot of stage st+3 (= that of stage st)
-  auto steady = [&](auto curc) __attribute__((always_inline)) {      // stages st+1, st+2 exist and st+3 is a full stage
-    constexpr int CUR = decltype(curc)::value;
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NP) : "memory");
-    issue_full(si);
-    load_frags(std::integral_constant<int, CUR ^ 1>{}, sr);
-    multiply(curc);
+  auto steady = [&](auto kc) __attribute__((always_inline)) {      // stages st+1, st+2 exist and st+3 is a full stage
+    constexpr int K = decltype(kc)::value;          // stage number modulo 6
+    char* const mine = K % 3 == 0 ? lds0 : (K % 3 == 1 ? lds1 : lds2);
+    const char* const next = (K + 1) % 3 == 0 ? lds0 : ((K + 1) % 3 == 1 ? lds1 : lds2);
+    wait_vm_then_barrier<NP, true>();
+    issue_full(mine);
+    load_frags(std::integral_constant<int, (K & 1) ^ 1>{}, next);
+    multiply(std::integral_constant<int, K & 1>{});
 #pragma unroll
     for (int k = 0; k < 16; ++k) {          // issue order: a transposing read behind every MFMA
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
-    bias_mma(curc);
-    sr = next3(sr);
-    si = next3(si);
+    bias_mma(std::integral_constant<int, K & 1>{});
   };
   auto general = [&](auto curc, int st) __attribute__((always_inline)) {
     constexpr int CUR = decltype(curc)::value;
@@ -538,7 +546,7 @@ __global__ __launch_bounds__(64 * WM * WN) void lin_wgrad_kernel(WgArgs a) {
       if (st + 2 < nstage) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NP) : "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       if (st + 3 < nstage) issue_any(st + 3, si);
-      load_frags(std::integral_constant<int, CUR ^ 1>{}, sr);
+      load_frags(std::integral_constant<int, CUR ^ 1>{}, slot_ptr(sr));
     }
     multiply(curc);
     bias_mma(curc);
@@ -552,13 +560,12 @@ __global__ __launch_bounds__(64 * WM * WN) void lin_wgrad_kernel(WgArgs a) {
     if (nstage > 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NP) : "memory");      // stage 0 has landed
     else if (nstage > 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NP) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    load_frags(std::integral_constant<int, 0>{}, 0);
+    load_frags(std::integral_constant<int, 0>{}, lds0);
     int st = 0;
 #pragma unroll 1
-    for (; st + 4 < nfull; st += 2) {
-      steady(std::integral_constant<int, 0>{});
-      steady(std::integral_constant<int, 1>{});
-    }
+    for (; st + 5 + 4 < nfull; st += 6) static_for<6>([&](auto kc) __attribute__((always_inline)) { steady(kc); });
+    sr = (st + 1) % 3;
+    si = st % 3;
 #pragma unroll 1
     for (; st < nstage; st += 2) {
       general(std::integral_constant<int, 0>{}, st);
@@ -899,8 +906,8 @@ __global__ __launch_bounds__(512) void lin_wgrad_rows_kernel(RowsArgs a) {
     }
   } else {
     auto sync_tile = [&](bool newer_in_flight) {
-      if (newer_in_flight) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NPW) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      if (newer_in_flight) wait_vm_then_barrier<NPW, false>();      // (the builtin form: see common.h)
+      else wait_vm_then_barrier<0, false>();
     };
     if (n > 0) issue_tile(tile_at(0), buf0);
     if (n > 1) issue_tile(tile_at(1), buf1);
