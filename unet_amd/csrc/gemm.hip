@@ -564,6 +564,12 @@ __global__ __launch_bounds__(64 * WM * WN) void lin_wgrad_kernel(WgArgs a) {
     int st = 0;
 #pragma unroll 1
     for (; st + 5 + 4 < nfull; st += 6) static_for<6>([&](auto kc) __attribute__((always_inline)) { steady(kc); });
+    static_for<5>([&](auto kc) __attribute__((always_inline)) {      // the (at most five) steady stages left over
+      if (st + 4 < nfull) {          // (uniform)
+        steady(kc);
+        ++st;
+      }
+    });
     sr = (st + 1) % 3;
     si = st % 3;
 #pragma unroll 1
