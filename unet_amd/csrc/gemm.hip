@@ -713,14 +713,14 @@ inline WgPlan plan_lin_wgrad(long M, int K, int N) {
   const long tiles = (long)p.gn * p.gk;
   // Token split: more ranges = more workgroups in flight and fewer stages each, but every range costs one
   // more fp32 copy of dw written and read back.  Pick the count with the lowest modelled time
-  // (0.5 us per 32-token stage at three workgroups per CU, 3 TB/s for the slabs; measured on MI355X).
+  // (0.35 us per 32-token stage at two workgroups per CU, 3 TB/s for the slabs; measured on MI355X).
   const double stages = (double)((M + 31) / 32);
   const double slab_us = 2.0 * 4.0 * p.N_pad * p.K_pad / 3.0e6;
   long best_s = 1;
   double best = 1e30;
   for (long s = 1; s <= 256 && s * 256 <= M + 255; s += (s < 8 ? 1 : 8)) {
-    const double rounds = (double)((tiles * s + 767) / 768);
-    const double t = stages / s * 0.5 * rounds + slab_us * s;
+    const double rounds = (double)((tiles * s + 511) / 512);
+    const double t = stages / s * 0.35 * rounds + slab_us * s;
     if (t < best) {
       best = t;
       best_s = s;
