@@ -243,6 +243,23 @@ def test_token_weight_gradient_gemm(shape):
     assert torch.equal(dw3, dw) or (B * H * Wd >= 2048 and rel(dw3, dw) < 1e-6)
 
 
+def test_token_weight_gradient_every_stage_count():
+    """The tile kernel's stage loop has a six-fold steady part, up to five single steady stages and a general tail,
+    and two fragment register sets that alternate: every stage count from 1 to 40 (the last stage ragged), and a
+    split token axis, against float64."""
+    from unet_amd import ops
+    dt = torch.bfloat16
+    K, N = 384, 512
+    g = torch.Generator().manual_seed(77)
+    for M in [32 * n - r for n in range(1, 41) for r in ((0,) if n % 3 else (0, 5))] + [32 * 700 + 3]:
+        x = (torch.randint(-4, 5, (1, 1, M, K), generator=g).float() * 0.25).to(dt)
+        dy = (torch.randint(-4, 5, (1, 1, M, N), generator=g).float() * 0.5).to(dt)
+        dw, db = ops.token_wgrad(x.cuda(), dy.cuda(), K, N)
+        want = dy.double().reshape(-1, N).t() @ x.double().reshape(-1, K)
+        assert rel(dw, want) < 1e-6, (M, rel(dw, want))
+        assert rel(db, dy.double().reshape(-1, N).sum(0)) < 1e-6, M
+
+
 @pytest.mark.parametrize("shape", [(2, 8, 8, 768, 512), (1, 16, 12, 512, 256), (3, 5, 7, 256, 128), (2, 64, 64, 128, 64)])
 def test_conv_transpose_gemm_with_shuffled_stores(shape):
     """ConvTranspose2d(k=2, s=2) + bias as one GEMM launch whose epilogue stores each value at its shuffled pixel:

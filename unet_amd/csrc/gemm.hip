@@ -572,6 +572,10 @@ __global__ __launch_bounds__(64 * WM * WN) void lin_wgrad_kernel(WgArgs a) {
     });
     sr = (st + 1) % 3;
     si = st % 3;
+    if ((st & 1) && st < nstage) {          // (uniform) stage st's fragments are in register set st & 1
+      general(std::integral_constant<int, 1>{}, st);
+      ++st;
+    }
 #pragma unroll 1
     for (; st < nstage; st += 2) {
       general(std::integral_constant<int, 0>{}, st);
