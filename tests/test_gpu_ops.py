@@ -287,6 +287,26 @@ def test_bn_bwd_sums_from_the_data_gradient_conv(shape):
         ops.bn_act_bwd(g1, y, sc, sh, mean, invstd, torch.ones(B, C, device="cuda"), relu=True, presummed=parts)
 
 
+def test_bn_bwd_sums_entry_point_refuses_what_it_does_not_cover():
+    """float32, 32- / 48-channel blocks and a y of another shape are refused with an error, not computed wrongly."""
+    from unet_amd import ops
+    w = torch.randn(96, 96, 3, 3, generator=torch.Generator().manual_seed(1)) * 0.1
+    assert not ops.conv_bwd_data_bnsums_supported(ops.PackedConv(w.cuda(), torch.float32, transpose=True), torch.float32)
+    w48 = torch.randn(64, 48, 3, 3, generator=torch.Generator().manual_seed(2)) * 0.1
+    p48 = ops.PackedConv(w48.cuda(), torch.bfloat16, transpose=True)       # 48 outputs: the 48-channel block
+    assert not ops.conv_bwd_data_bnsums_supported(p48, torch.bfloat16)
+    dt = torch.bfloat16
+    dy = torch.zeros(1, 8, 8, 64, dtype=dt, device="cuda")
+    y = torch.zeros(1, 8, 8, 48, dtype=dt, device="cuda")
+    v = torch.ones(48, device="cuda")
+    with pytest.raises(ValueError, match="channel block"):
+        ops.conv_bwd_data_bnsums(dy, p48, y, v, v, v, v)
+    pw = ops.PackedConv(w.cuda(), dt, transpose=True)
+    with pytest.raises(ValueError):
+        ops.conv_bwd_data_bnsums(torch.zeros(1, 8, 8, 96, dtype=dt, device="cuda"), pw,
+                                 torch.zeros(1, 8, 4, 96, dtype=dt, device="cuda"), v, v, v, v)
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("hw", [((8, 8), (16, 16)), ((6, 9), (12, 18)), ((12, 18), (25, 36)), ((1, 1), (3, 3)),
                                 ((3, 5), (7, 11)), ((1, 1), (2, 2)), ((2, 3), (4, 6)), ((1, 5), (2, 10)),
