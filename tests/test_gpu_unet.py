@@ -292,3 +292,31 @@ def test_repeatable_bitwise():
         res.append((out.clone(), [p.grad.clone() for p in m.parameters()]))
     assert torch.equal(res[0][0], res[1][0])
     assert all(torch.equal(a, b) for a, b in zip(res[0][1], res[1][1]))
+
+
+def test_backward_fusions_agree_with_the_separate_passes(monkeypatch):
+    """The two fusions of the backward pass that are switched per layer - the pool gradient formed inside the
+    BatchNorm-backward passes (same bits as the stored tensor) and the BatchNorm-backward sums left by the
+    data-gradient conv (another summation order: 1e-5 of the sums) - against the separate passes on the 48-feature
+    case, where every layer from 96 channels up takes the second one."""
+    from unet_amd import unet as U
+    m, sd, x, y = build("f48", torch.bfloat16)
+    m.train()
+    m.dropout_masks_override = [None] * 9
+    res = {}
+    for sums, pool in ((True, True), (False, True), (False, False)):
+        monkeypatch.setattr(U, "FUSE_BN_SUMS", sums)
+        monkeypatch.setattr(U, "FUSE_POOL_BWD", pool)
+        m.load_state_dict(sd)
+        m.zero_grad()
+        out = m(x.cuda())
+        ((out - y.cuda()) ** 2).mean().backward()
+        res[(sums, pool)] = (out.clone(), {n: p.grad.clone() for n, p in m.named_parameters()})
+    base_out, base = res[(False, False)]
+    assert torch.equal(res[(False, True)][0], base_out) and torch.equal(res[(True, True)][0], base_out)
+    assert all(torch.equal(res[(False, True)][1][n], g) for n, g in base.items())      # the pool fusion: same bits
+    # (bf16 storage: a last-place change of a sum flips a rounding here and there, and the layers below amplify it -
+    #  on this case the bf16 step as a whole sits 0.4..0.6 from its fp32 run, see the header)
+    errs = sorted(rel(res[(True, True)][1][n], g) for n, g in base.items())
+    print("fused-sums vs separate, relative L2 per parameter: median %.2e, worst %.2e" % (errs[len(errs) // 2], errs[-1]))
+    assert errs[len(errs) // 2] < 1e-2 and errs[-1] < 5e-2, errs[-5:]
