@@ -930,9 +930,11 @@ WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int dtype, int ks, boo
   // Pixel split: one workgroup per CU at a time, so the grid should be a whole number of rounds of
   // 256 (and at least two, when there are tiles enough); every split costs one more partial slab
   // to write and read back.  Score = fill of the last round, discounted by the slab traffic
-  // relative to the multiply (at ~700 TFLOP/s and ~3 TB/s).
+  // relative to the multiply (at ~700 TFLOP/s and ~0.9 TB/s: inside a training step the slabs are written and summed
+  // beside the HBM-bound passes of the main stream - priced at the 3 TB/s they reach alone, the UNet step measured
+  // 0.06...0.17 ms slower).
   const double t_mul = 2.0 * B * H * W * ks * ks * (double)p.Ci_pad * p.Co_pad / 700e12;
-  const double t_slab = 8.0 * ks * ks * (double)p.Ci_pad * p.Co_pad / 3e12;
+  const double t_slab = 8.0 * ks * ks * (double)p.Ci_pad * p.Co_pad / 0.9e12;
   int s = 1;
   double best = -1.0;
   for (int c = 1; c <= 256 && c <= p.ntiles; c += (c < 32 ? 1 : 8)) {
