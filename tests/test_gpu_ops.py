@@ -119,6 +119,29 @@ def test_wgrad_whole_pixel_kernel(shape):
         assert torch.equal(dw, ops.conv_wgrad(xd, gd, Ci, Co, 3))
 
 
+@pytest.mark.parametrize("shape", [(16, 128, 128, 64, 64, 3), (16, 128, 128, 64, 32, 3), (12, 100, 130, 40, 24, 3),
+                                   (16, 128, 128, 64, 32, 1)])
+def test_wgrad_many_slab_reduction(shape):
+    """A narrow layer at full resolution: a small dw under many pixel splits, summed by the slab-lane reduction
+    (from 32 slabs on) instead of the slab-after-slab one.  Against autograd, the same bits every run, accumulate."""
+    from unet_amd import ops
+    dt = torch.bfloat16
+    B, H, W, Ci, Co, ks = shape
+    if shape[:5] == (16, 128, 128, 64, 64):     # this one is known to take the many-slab path: 64x9x64 floats a slab
+        ws = ops._lib.load().unetk_conv_wgrad_workspace_bytes(B, H, W, Ci, Co, ks, 1)
+        assert ws // (64 * 9 * 64 * 4) >= 32
+    x = rnd((B, Ci, H, W), 71, dt)
+    gy = rnd((B, Co, H, W), 72, dt)
+    wr = torch.zeros((Co, Ci, ks, ks), requires_grad=True)
+    F.conv2d(x, wr, None, padding=ks // 2).backward(gy)
+    xd, gd = nhwc(x, dt), nhwc(gy, dt)
+    dw = ops.conv_wgrad(xd, gd, Ci, Co, ks)
+    assert rel(dw.cpu(), wr.grad) < TOL[dt]
+    assert torch.equal(dw, ops.conv_wgrad(xd, gd, Ci, Co, ks))
+    dw2 = ops.conv_wgrad(xd, gd, Ci, Co, ks, dw=dw.clone(), accumulate=True)
+    assert rel(dw2.cpu(), 2 * wr.grad) < TOL[dt]
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("shape", [(144, 96), (144, 48), (192, 96), (128, 64)])
 def test_conv_split_outputs(dt, shape):

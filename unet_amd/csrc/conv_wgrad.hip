@@ -481,6 +481,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(WgradArgs a) {
 // element over the slabs in a fixed order (bitwise reproducible) reading 128-byte runs along ci, the
 // tile turns in LDS, and the results leave as one contiguous run of dw per output channel.
 constexpr int WR_ROWS3 = 4;                      // output channels per workgroup, 3x3
+constexpr int WR_MANY_SLABS = 32;                // from this many slabs on (and a dw of at most 2^20 elements) the slab-lane reduction runs instead
 constexpr int WR_MAX = WR_ROWS3 * 288;           // elements per workgroup: rows x (9 taps x 32 channels), or 8 rows x 32 channels
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab,
                                                            float* __restrict__ dw, int nslab, int Co, int Ci,
@@ -513,6 +514,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (co0 + row < Co) {
       const float* p = slab + ((long)(co0 + row) * taps + tap) * Ci_pad + chunk * 32 + cl;
       int i = 0;
+      // (a narrow layer at full resolution has a handful of these workgroups and hundreds of slabs: its time is the
+      //  chain of load latencies, so sixteen slabs are in flight while there are that many)
+      for (; i + 16 <= nslab; i += 16) {
+        f32x4 v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = *reinterpret_cast<const f32x4*>(p + (i + j) * stride);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s = s + v[j];
+      }
       for (; i + 4 <= nslab; i += 4) {
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + i * stride), v1 = *reinterpret_cast<const f32x4*>(p + (i + 1) * stride);
         const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (i + 2) * stride), v3 = *reinterpret_cast<const f32x4*>(p + (i + 3) * stride);
@@ -1067,6 +1077,15 @@ static int wgrad_impl(const void* in, int ldin, const void* dy, int lddy, float*
   else
     rc = ks == 3 ? launch_wgrad<float, 3>(a, p, stream) : launch_wgrad<float, 1>(a, p, stream);
   if (rc != UNETK_OK) return rc;
+  if (dbias == nullptr && p.nsplit >= WR_MANY_SLABS && (long)Co * Ci * ks * ks <= (1L << 20)) {
+    // a small dw under many slabs (a narrow layer at full resolution): the slab-lane reduction, whose chain of
+    // dependent loads is nslab/64 long instead of nslab/4 (same bits every run; the choice depends on the shape only)
+    const long nb = cdiv((long)Co * ks * ks * (p.Ci_pad / 4), 16);
+    hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a.slab, dw, p.nsplit, Co, Ci,
+                       p.Co_pad, p.Ci_pad, ks * ks, accumulate);
+    UNETK_CHECK_LAUNCH();
+    return UNETK_OK;
+  }
   const long nblocks = (long)cdiv(Co, ks == 1 ? 8 : WR_ROWS3) * (p.Ci_pad / 32);
   const long nbias = dbias ? cdiv(Co, 256) : 0;      // trailing workgroups sum the bias slabs
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(nblocks + nbias)), dim3(256), 0, stream, a.slab, dw,
