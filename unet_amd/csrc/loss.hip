@@ -121,20 +121,30 @@ __global__ __launch_bounds__(LT) void pixgrad_fwd_kernel(const float* __restrict
 // Single workgroup: sum the partials in double, emit loss parts and backward coefficients.
 __global__ __launch_bounds__(LT) void pixgrad_finalize_kernel(const float* __restrict__ partials, int nblk,
                                                               LossCfg c, float* __restrict__ res) {
-  __shared__ double red[LT];
+  // all NQ quantities in one sweep: a thread sums its rows of every quantity in row order, then thread q adds the LT
+  // thread sums of quantity q in thread order (one quantity after the other, with two barriers each, gave the same
+  // bits in five times the time: this launch sits between the loss kernels of every step)
+  __shared__ double red[NQ][LT];
   __shared__ double tot[NQ];
-  for (int q = 0; q < NQ; ++q) {
-    double s = 0.0;
-    for (int i = threadIdx.x; i < nblk; i += LT) s += (double)partials[(long)i * NQ + q];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double t = 0.0;
-      for (int i = 0; i < LT; ++i) t += red[i];
-      tot[q] = t;
-    }
-    __syncthreads();
+  double s[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) s[q] = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += LT) {
+    float v[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) v[q] = partials[(long)i * NQ + q];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) s[q] += (double)v[q];
   }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) red[q][threadIdx.x] = s[q];
+  __syncthreads();
+  if (threadIdx.x < NQ) {
+    double t = 0.0;
+    for (int i = 0; i < LT; ++i) t += red[threadIdx.x][i];
+    tot[threadIdx.x] = t;
+  }
+  __syncthreads();
   if (threadIdx.x != 0) return;
   const double N = (double)c.B * c.H * c.W;
   const double npos = tot[2];
@@ -299,7 +309,21 @@ __global__ __launch_bounds__(256) void spectral_finalize_kernel(const float* __r
     const int b = b0 + threadIdx.x;
     if (b < B) {
       double s = 0.0, ws = 0.0;
-      for (int i = 0; i < nblk; ++i) {
+      int i = 0;
+      for (; i + 8 <= nblk; i += 8) {          // eight loads of each list in flight, added in order
+        float v[8], u[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          v[k] = partials[b * nblk + i + k];
+          u[k] = wsum[b * nblk + i + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          s += (double)v[k];
+          ws += (double)u[k];
+        }
+      }
+      for (; i < nblk; ++i) {
         s += (double)partials[b * nblk + i];
         ws += (double)wsum[b * nblk + i];
       }

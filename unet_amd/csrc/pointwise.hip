@@ -523,11 +523,28 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_coef_kernel(const float* __re
   const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;
   const int c = blockIdx.x * 4 + cl;
   double s = 0.0, q = 0.0;
-  if (c < C)
-    for (int r = rl; r < nparts; r += 64) {
+  if (c < C) {
+    // (this launch sits between the reduction and the apply pass of every BatchNorm backward: eight rows of a lane
+    //  are in flight, added in row order as a one-by-one loop would)
+    int r = rl;
+    for (; r + 64 * 7 < nparts; r += 64 * 8) {
+      float a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a[u] = partials[((long)(r + 64 * u) * 2) * C + c];
+        b[u] = partials[((long)(r + 64 * u) * 2 + 1) * C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        s += (double)a[u];
+        q += (double)b[u];
+      }
+    }
+    for (; r < nparts; r += 64) {
       s += (double)partials[((long)r * 2) * C + c];
       q += (double)partials[((long)r * 2 + 1) * C + c];
     }
+  }
   red[0][rl][cl] = s;
   red[1][rl][cl] = q;
   __syncthreads();

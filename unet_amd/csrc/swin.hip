@@ -363,29 +363,48 @@ __global__ __launch_bounds__(256) void token_reduce_kernel(const T* __restrict__
   }
 }
 
+// One workgroup = 16 channels x 16 row lanes: a wave reads four rows of 64 consecutive bytes, a lane keeps eight rows
+// in flight and adds them in row order (double), then the 16 lane sums are added in lane order.
 __device__ __forceinline__ void partial_sum2_body(const float* __restrict__ partials, int nparts, int C,
                                                   float* out0, float* out1) {
-  __shared__ double red[2][64][4];
-  const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;
-  const int c = blockIdx.x * 4 + cl;
+  __shared__ double red[2][16][16];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   double s = 0.0, q = 0.0;
-  if (c < C)
-    for (int r = rl; r < nparts; r += 64) {
-      s += (double)partials[((long)r * 2) * C + c];
-      q += (double)partials[((long)r * 2 + 1) * C + c];
+  if (c < C) {
+    const float* p = partials + c;
+    const long row = 2L * C;
+    int r = rl;
+    for (; r + 16 * 7 < nparts; r += 16 * 8) {
+      float a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a[u] = p[(long)(r + 16 * u) * row];
+        b[u] = p[(long)(r + 16 * u) * row + C];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        s += (double)a[u];
+        q += (double)b[u];
+      }
     }
+    for (; r < nparts; r += 16) {
+      s += (double)p[(long)r * row];
+      q += (double)p[(long)r * row + C];
+    }
+  }
   red[0][rl][cl] = s;
   red[1][rl][cl] = q;
   __syncthreads();
-  if (threadIdx.x < 4 && blockIdx.x * 4 + threadIdx.x < C) {
-    const int cc = blockIdx.x * 4 + threadIdx.x;
+  if (rl == 0 && c < C) {
     double ss = 0.0, qq = 0.0;
-    for (int r = 0; r < 64; ++r) {
-      ss += red[0][r][threadIdx.x];
-      qq += red[1][r][threadIdx.x];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      ss += red[0][r][cl];
+      qq += red[1][r][cl];
     }
-    if (out0) out0[cc] = (float)ss;
-    if (out1) out1[cc] = (float)qq;
+    if (out0) out0[c] = (float)ss;
+    if (out1) out1[c] = (float)qq;
   }
 }
 
@@ -400,7 +419,7 @@ __global__ __launch_bounds__(256) void partial_sum2_kernel(const float* __restri
 __global__ __launch_bounds__(256) void partial_sum2_batched_kernel(const long* __restrict__ jobs) {
   const long* j = jobs + 5L * blockIdx.y;
   const int C = (int)j[2];
-  if ((int)blockIdx.x * 4 >= C) return;
+  if ((int)blockIdx.x * 16 >= C) return;
   partial_sum2_body(reinterpret_cast<const float*>(j[0]), (int)j[1], C, reinterpret_cast<float*>(j[3]),
                     reinterpret_cast<float*>(j[4]));
 }
@@ -890,22 +909,45 @@ __global__ __launch_bounds__(64) void window_attn_bwd_kernel(const T* __restrict
   }
 }
 
-// dtable[bin][head] = sum over (b, window) of the partials, fixed order
+// dtable[bin][head] = sum over (b, window) of the partials, fixed order.  One workgroup = 16 bins x 16 window lanes
+// (a wave reads 64 consecutive bytes of four windows); a lane keeps eight windows in flight and adds them in window
+// order, then the 16 lane sums are added in lane order.
+constexpr int DT_BIN_GROUPS = (225 + 15) / 16;
 __device__ __forceinline__ void dtable_reduce_body(const float* __restrict__ partials, int nwin, int heads,
                                                    float* __restrict__ dtable) {
-  const int bin = blockIdx.x, head = blockIdx.y;
+  __shared__ float red[16][16];
+  const int bl = threadIdx.x & 15, wl = threadIdx.x >> 4;
+  const int bin = blockIdx.x * 16 + bl, head = blockIdx.y;
   float s = 0.f;
-  for (int w = threadIdx.x; w < nwin; w += 64) s += partials[((long)w * heads + head) * 225 + bin];
-  s = wave_sum(s);
-  if (threadIdx.x == 0) dtable[bin * heads + head] = s;
+  if (bin < 225) {
+    const float* p = partials + (long)head * 225 + bin;
+    const long stride = (long)heads * 225;
+    int w = wl;
+    for (; w + 16 * 7 < nwin; w += 16 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(long)(w + 16 * u) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; w < nwin; w += 16) s += p[(long)w * stride];
+  }
+  red[wl][bl] = s;
+  __syncthreads();
+  if (wl == 0 && bin < 225) {
+    float t = red[0][bl];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += red[k][bl];
+    dtable[bin * heads + head] = t;
+  }
 }
-__global__ __launch_bounds__(64) void dtable_reduce_kernel(const float* __restrict__ partials, int nwin, int heads,
-                                                           float* __restrict__ dtable) {
+__global__ __launch_bounds__(256) void dtable_reduce_kernel(const float* __restrict__ partials, int nwin, int heads,
+                                                            float* __restrict__ dtable) {
   dtable_reduce_body(partials, nwin, heads, dtable);
 }
 // The same for every attention layer of a backward pass in one launch: blockIdx.z = job, four int64 per job =
 // partials, windows (B * nW), heads, dtable.
-__global__ __launch_bounds__(64) void dtable_reduce_batched_kernel(const long* __restrict__ jobs) {
+__global__ __launch_bounds__(256) void dtable_reduce_batched_kernel(const long* __restrict__ jobs) {
   const long* j = jobs + 4L * blockIdx.z;
   const int heads = (int)j[2];
   if ((int)blockIdx.y >= heads) return;
@@ -1014,7 +1056,7 @@ int unetk_layernorm_bwd_partials(const void* dy, const void* x, const float* gam
 
 int unetk_partial_sums_batched(const int64_t* jobs, int njobs, int max_C, hipStream_t stream) {
   UNETK_CHECK_ARG(jobs && njobs > 0 && njobs <= 65535 && max_C > 0, "partial_sums_batched: bad arguments");
-  hipLaunchKernelGGL(partial_sum2_batched_kernel, dim3(cdiv(max_C, 4), njobs), dim3(256), 0, stream,
+  hipLaunchKernelGGL(partial_sum2_batched_kernel, dim3(cdiv(max_C, 16), njobs), dim3(256), 0, stream,
                      reinterpret_cast<const long*>(jobs));
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
@@ -1048,7 +1090,7 @@ static int layernorm_bwd_impl(const void* dy, const void* x, const float* gamma,
 #undef LN_BWD
     UNETK_CHECK_LAUNCH();
     if (want_sums) {
-      hipLaunchKernelGGL(partial_sum2_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, partials, cdiv(ntok, chunk), C,
+      hipLaunchKernelGGL(partial_sum2_kernel, dim3(cdiv(C, 16)), dim3(256), 0, stream, partials, cdiv(ntok, chunk), C,
                          dgamma, dbeta);
       UNETK_CHECK_LAUNCH();
     }
@@ -1064,7 +1106,7 @@ static int layernorm_bwd_impl(const void* dy, const void* x, const float* gamma,
                                          (const T*)dy, C, (const T*)x, mean, rstd, (long)ntok, C, CS, chunk,
                                          partials));
     UNETK_CHECK_LAUNCH();
-    hipLaunchKernelGGL(partial_sum2_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, partials, nb, C, dgamma, dbeta);
+    hipLaunchKernelGGL(partial_sum2_kernel, dim3(cdiv(C, 16)), dim3(256), 0, stream, partials, nb, C, dgamma, dbeta);
     UNETK_CHECK_LAUNCH();
   }
   return UNETK_OK;
@@ -1083,7 +1125,7 @@ int unetk_channel_sum(const void* x, int ld, int64_t ntok, int C, float* out, fl
                                        (const T*)x, ld, (const T*)nullptr, (const float*)nullptr,
                                        (const float*)nullptr, (long)ntok, C, CS, chunk, partials));
   UNETK_CHECK_LAUNCH();
-  hipLaunchKernelGGL(partial_sum2_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, partials, nb, C, out,
+  hipLaunchKernelGGL(partial_sum2_kernel, dim3(cdiv(C, 16)), dim3(256), 0, stream, partials, nb, C, out,
                      (float*)nullptr);
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
@@ -1228,7 +1270,7 @@ int unetk_window_attn_bwd(const void* qkv, const void* dout, void* dqkv, const f
     UNETK_CHECK_LAUNCH();
   }
   if (dtable != nullptr) {      // (null: the caller sums the partials later, unetk_dtable_reduce_batched)
-    hipLaunchKernelGGL(dtable_reduce_kernel, dim3(225, heads), dim3(64), 0, stream, dtable_partials, nwin, heads,
+    hipLaunchKernelGGL(dtable_reduce_kernel, dim3(DT_BIN_GROUPS, heads), dim3(256), 0, stream, dtable_partials, nwin, heads,
                        dtable);
     UNETK_CHECK_LAUNCH();
   }
@@ -1238,7 +1280,7 @@ int unetk_window_attn_bwd(const void* qkv, const void* dout, void* dqkv, const f
 int unetk_dtable_reduce_batched(const int64_t* jobs, int njobs, int max_heads, hipStream_t stream) {
   UNETK_CHECK_ARG(jobs && njobs > 0 && njobs <= 65535 && max_heads > 0 && max_heads <= 65535,
                   "dtable_reduce_batched: bad arguments");
-  hipLaunchKernelGGL(dtable_reduce_batched_kernel, dim3(225, max_heads, njobs), dim3(64), 0, stream,
+  hipLaunchKernelGGL(dtable_reduce_batched_kernel, dim3(DT_BIN_GROUPS, max_heads, njobs), dim3(256), 0, stream,
                      reinterpret_cast<const long*>(jobs));
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;

@@ -87,16 +87,21 @@ class OptimizedUNet(nn.Module):
         if self.dropout_masks_override is not None:
             return [None if m is None else m.to(device=device, dtype=torch.float32).contiguous()
                     for m in self.dropout_masks_override]
+        # one draw and one scaling per distinct rate for all blocks (each block's (B, c) factors are a contiguous
+        # piece of it), not two small launches per block
+        plan = [(getattr(self, name)[6].p, getattr(self, name)[3].out_channels) for name in BLOCKS]
+        flat = {}
+        for p in {p for p, _ in plan if p != 0.0}:
+            n = sum(B * c for q, c in plan if q == p)
+            flat[p] = [torch.empty(n, dtype=torch.float32, device=device).bernoulli_(1 - p).div_(1 - p), 0]
         masks = []
-        for name in BLOCKS:
-            drop = getattr(self, name)[6]
-            p = drop.p
-            c = getattr(self, name)[3].out_channels
+        for p, c in plan:
             if p == 0.0:
                 masks.append(None)
-            else:
-                keep = torch.empty((B, c), dtype=torch.float32, device=device).bernoulli_(1 - p)
-                masks.append(keep.div_(1 - p))
+                continue
+            buf, off = flat[p]
+            masks.append(buf[off:off + B * c].view(B, c))
+            flat[p][1] = off + B * c
         return masks
 
 
