@@ -46,6 +46,29 @@ def test_multiloss_matches_oracle_and_golden(golden, si):
             assert rel(sub(pd.grad.cpu(), 2048), g[key + ".grad"]) < 1e-4, key
 
 
+@pytest.mark.parametrize("shape", [(2, 19, 30), (1, 9, 7), (2, 20, 36)])
+def test_multiloss_widths_with_and_without_the_four_pixel_kernels(shape):
+    """Image widths that are not a multiple of four take the one-pixel-per-thread kernels, the others (every golden
+    shape among them) the four-pixel ones: both against the oracle, every preset, with and without weights."""
+    from unet_amd.losses import MultiLossFunction
+    B, H, Wd = shape
+    _, y, w = W.synthetic_batch(B, 1, H, Wd, seed=31)
+    p = W.synthetic_batch(B, 1, H, Wd, seed=32)[1] * 0.7 + 0.3 * y
+    for wt in (None, w):
+        for cname, kw in LOSS_CFGS.items():
+            cfg = loss_oracle.preset(**kw)
+            crit = MultiLossFunction(cfg).cuda()
+            pd = p.cuda().requires_grad_(True)
+            total, parts = crit(pd, y.cuda(), None if wt is None else wt.cuda())
+            total.backward()
+            po = p.clone().requires_grad_(True)
+            o_total, o_parts = loss_oracle.multi_loss(cfg, po, y, wt)
+            o_total.backward()
+            for k in ("pixel", "gradient", "spectral", "total"):
+                assert abs(parts[k] - o_parts[k]) <= 1e-4 * max(abs(o_parts[k]), 1e-6), (shape, cname, k)
+            assert rel(pd.grad, po.grad) < 1e-4, (shape, cname)
+
+
 def test_sub_losses_and_errors():
     from unet_amd.losses import GradientLoss, MultiLossFunction, SpectralLoss, TIDWeightedLoss
     p, y, w = loss_inputs(0)

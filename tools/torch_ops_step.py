@@ -2,7 +2,7 @@
 """Which torch operators (and how many device copies / fills) one eager trainer step still launches beside the
 library's own kernels: the headline UNet step or the Swin step under torch.profiler, operators by call count.
 
-    python tools/torch_ops_step.py train|swin [batch]
+    python tools/torch_ops_step.py train [batch] [regex: also list every operator / kernel whose name matches]
 """
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -47,6 +47,10 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     torch.cuda.synchronize()
 rows = sorted(prof.key_averages(), key=lambda e: -e.count)
 print(f"{'operator':60s} {'calls/step':>10s} {'cpu us/call':>12s} {'gpu us/call':>12s}")
-for e in rows[:60]:
+import re
+flt = re.compile(sys.argv[3]) if len(sys.argv) > 3 else None
+for i, e in enumerate(rows):
+    if i >= 60 and not (flt and flt.search(e.key)):
+        continue
     gpu = getattr(e, "device_time_total", 0.0) / max(e.count, 1)
     print(f"{e.key[:60]:60s} {e.count / N:10.1f} {e.cpu_time_total / max(e.count, 1):12.1f} {gpu:12.1f}")

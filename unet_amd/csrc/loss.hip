@@ -118,6 +118,102 @@ __global__ __launch_bounds__(LT) void pixgrad_fwd_kernel(const float* __restrict
   }
 }
 
+// Four consecutive pixels of a row per thread (W % 4 == 0, 16-byte aligned images, no gradient part or the Sobel
+// one): a row of the 3x3 stencil is one 16-byte load and two edge values per image instead of three loads per pixel.
+// Every pixel's values come from the expressions of pixgrad_fwd_kernel; only the order in which a thread adds its
+// pixels into the sums differs (another assignment of pixels to threads).
+struct Row6 {
+  float v[6];
+};
+__device__ __forceinline__ Row6 diff_row6(const float* __restrict__ p, const float* __restrict__ t, int H, int W,
+                                          int y, int x0) {
+  Row6 r;
+  if (y < 0 || y >= H) {      // zero padding of F.conv2d(padding=1)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) r.v[k] = 0.f;
+    return r;
+  }
+  const long o = (long)y * W + x0;
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p + o), b = *reinterpret_cast<const f32x4*>(t + o);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) r.v[k + 1] = a[k] - b[k];
+  r.v[0] = x0 > 0 ? p[o - 1] - t[o - 1] : 0.f;
+  r.v[5] = x0 + 4 < W ? p[o + 4] - t[o + 4] : 0.f;
+  return r;
+}
+
+__global__ __launch_bounds__(LT) void pixgrad_fwd_vec4_kernel(const float* __restrict__ pred,
+                                                              const float* __restrict__ target,
+                                                              const float* __restrict__ w, LossCfg c,
+                                                              float* __restrict__ gx_out, float* __restrict__ gy_out,
+                                                              float* __restrict__ partials) {
+  __shared__ float red[LT / 64];
+  float s[NQ];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) s[i] = 0.f;
+  const long nquad = (long)c.B * c.H * c.W / 4;
+  const int hw = c.H * c.W, wq = c.W / 4;
+  for (long q = (long)blockIdx.x * LT + threadIdx.x; q < nquad; q += (long)gridDim.x * LT) {
+    const long idx = q * 4;
+    const int b = idx / hw;
+    const int r = idx - (long)b * hw;
+    const int y = r / c.W, x0 = r - y * c.W;
+    const float* p = pred + (long)b * hw;
+    const float* t = target + (long)b * hw;
+    const Row6 d1 = diff_row6(p, t, c.H, c.W, y, x0);
+    f32x4 wv = {0.f, 0.f, 0.f, 0.f};
+    if (c.has_w) wv = *reinterpret_cast<const f32x4*>(w + idx);
+    float gxv[4] = {0.f, 0.f, 0.f, 0.f}, gyv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c.grad_method == 1) {
+      const Row6 d0 = diff_row6(p, t, c.H, c.W, y - 1, x0), d2 = diff_row6(p, t, c.H, c.W, y + 1, x0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float d00 = d0.v[k], d01 = d0.v[k + 1], d02 = d0.v[k + 2];
+        const float d10 = d1.v[k], d12 = d1.v[k + 2];
+        const float d20 = d2.v[k], d21 = d2.v[k + 1], d22 = d2.v[k + 2];
+        gxv[k] = (d02 - d00) + 2.f * (d12 - d10) + (d22 - d20);
+        gyv[k] = (d20 - d00) + 2.f * (d21 - d01) + (d22 - d02);
+      }
+      *reinterpret_cast<f32x4*>(gx_out + idx) = f32x4{gxv[0], gxv[1], gxv[2], gxv[3]};
+      *reinterpret_cast<f32x4*>(gy_out + idx) = f32x4{gyv[0], gyv[1], gyv[2], gyv[3]};
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float d = d1.v[k + 1];
+      const float L = c.pixel_mae ? fabsf(d) : d * d;
+      s[0] += L;
+      if (c.has_w && wv[k] > 0.f) {
+        s[1] += L * (wv[k] * c.tid_scale);
+        s[2] += 1.f;
+      }
+      if (c.grad_method == 1) {
+        const float g = gxv[k] * gxv[k] + gyv[k] * gyv[k];
+        s[3] += g;
+        if (c.has_w && wv[k] > 0.f) s[4] += g * wv[k];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const float t = block_sum(s[i], red);
+    if (threadIdx.x == 0) partials[(long)blockIdx.x * NQ + i] = t;
+  }
+}
+
+// the one-pixel-per-thread kernel or, where the images allow it, the four-pixel one (the choice depends on the
+// shape, the gradient method and the alignment of the images only)
+inline bool loss_vec4_ok(const LossCfg& c, const void* a, const void* b, const void* w, const void* g0, const void* g1) {
+  auto al = [](const void* p) { return p == nullptr || ((uintptr_t)p % 16) == 0; };
+  return c.W % 4 == 0 && c.grad_method != 2 && al(a) && al(b) && al(w) && al(g0) && al(g1);
+}
+inline void launch_pixgrad_fwd(const float* pred, const float* target, const float* w, const LossCfg& c, float* gx,
+                               float* gy, float* partials, int nblk, hipStream_t stream) {
+  if (loss_vec4_ok(c, pred, target, w, gx, gy))
+    hipLaunchKernelGGL(pixgrad_fwd_vec4_kernel, dim3(nblk), dim3(LT), 0, stream, pred, target, w, c, gx, gy, partials);
+  else
+    hipLaunchKernelGGL(pixgrad_fwd_kernel, dim3(nblk), dim3(LT), 0, stream, pred, target, w, c, gx, gy, partials);
+}
+
 // Single workgroup: sum the partials in double, emit loss parts and backward coefficients.
 __global__ __launch_bounds__(LT) void pixgrad_finalize_kernel(const float* __restrict__ partials, int nblk,
                                                               LossCfg c, float* __restrict__ res) {
@@ -258,6 +354,98 @@ __global__ void pixgrad_bwd_kernel(const float* __restrict__ pred, const float* 
   }
   g *= go;
   dpred[idx] = accumulate ? dpred[idx] + g : g;
+}
+
+// The same backward for four consecutive pixels of a row per thread (W % 4 == 0, 16-byte aligned images, no gradient
+// part or the Sobel one): the 3x3 neighbourhoods of the Sobel maps and the weights are three 16-byte loads and six
+// edge values per image.  Every pixel's terms are added in the order of pixgrad_bwd_kernel.
+__device__ __forceinline__ Row6 load_row6(const float* __restrict__ a, int H, int W, int y, int x0) {
+  Row6 r;
+  if (y < 0 || y >= H) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) r.v[k] = 0.f;
+    return r;
+  }
+  const long o = (long)y * W + x0;
+  const f32x4 v = *reinterpret_cast<const f32x4*>(a + o);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) r.v[k + 1] = v[k];
+  r.v[0] = x0 > 0 ? a[o - 1] : 0.f;
+  r.v[5] = x0 + 4 < W ? a[o + 4] : 0.f;
+  return r;
+}
+
+__global__ __launch_bounds__(256) void pixgrad_bwd_vec4_kernel(const float* __restrict__ pred,
+                                                               const float* __restrict__ target,
+                                                               const float* __restrict__ w, LossCfg c,
+                                                               const float* __restrict__ gx,
+                                                               const float* __restrict__ gy,
+                                                               const float* __restrict__ res,
+                                                               const float* __restrict__ gout, int use_grad,
+                                                               float* __restrict__ dpred, int accumulate) {
+  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long npix = (long)c.B * c.H * c.W;
+  const long idx = q * 4;
+  if (idx >= npix) return;
+  const int hw = c.H * c.W;
+  const int b = idx / hw;
+  const int r = idx - (long)b * hw;
+  const int y = r / c.W, x0 = r - y * c.W;
+  const float go = gout[0];
+  const f32x4 pv = *reinterpret_cast<const f32x4*>(pred + idx), tv = *reinterpret_cast<const f32x4*>(target + idx);
+  const bool pixel_w = res[5] != 0.f;
+  const bool sobel = use_grad && c.grad_method == 1;
+  const bool weighted = sobel && res[7] != 0.f;
+  const long base = (long)b * hw;
+  Row6 W6[3], GX[3], GY[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) W6[a].v[k] = GX[a].v[k] = GY[a].v[k] = 0.f;
+  }
+  if (pixel_w || weighted) W6[1] = load_row6(w + base, c.H, c.W, y, x0);
+  if (sobel) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      GX[a] = load_row6(gx + base, c.H, c.W, y + a - 1, x0);
+      GY[a] = load_row6(gy + base, c.H, c.W, y + a - 1, x0);
+      if (weighted && a != 1) W6[a] = load_row6(w + base, c.H, c.W, y + a - 1, x0);
+    }
+  }
+  float out[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float d = pv[k] - tv[k];
+    float g = 0.f;
+    {   // pixel
+      const float dl = c.pixel_mae ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : 2.f * d;
+      float m = 1.f;
+      if (pixel_w) m = (W6[1].v[k + 1] > 0.f) ? W6[1].v[k + 1] : 0.f;
+      g += c.w_pixel * res[4] * m * dl;
+    }
+    if (sobel) {
+      float acc = 0.f;
+#pragma unroll
+      for (int a = -1; a <= 1; ++a)
+#pragma unroll
+        for (int bb = -1; bb <= 1; ++bb) {
+          const int ny = y + a, nx = x0 + k + bb;
+          if (ny < 0 || ny >= c.H || nx < 0 || nx >= c.W) continue;
+          const float wn = W6[a + 1].v[k + 1 + bb];
+          float m = 1.f;
+          if (weighted) m = (wn > 0.f) ? wn : 0.f;
+          const int ka = -a, kb = -bb;
+          const float sx = (float)(kb) * (ka == 0 ? 2.f : 1.f);
+          const float sy = (float)(ka) * (kb == 0 ? 2.f : 1.f);
+          acc += m * (GX[a + 1].v[k + 1 + bb] * sx + GY[a + 1].v[k + 1 + bb] * sy);
+        }
+      g += c.w_grad * res[6] * 2.f * acc;
+    }
+    out[k] = g * go;
+  }
+  f32x4 o = {out[0], out[1], out[2], out[3]};
+  if (accumulate) o += *reinterpret_cast<const f32x4*>(dpred + idx);
+  *reinterpret_cast<f32x4*>(dpred + idx) = o;
 }
 
 // ---------------------------------------------------------------- spectral loss (after the FFTs)
@@ -447,7 +635,7 @@ int unetk_loss_pixgrad_fwd(const float* pred, const float* target, const float* 
   LossCfg c = make_cfg(B, H, W, pixel_mae, grad_method, pixel_use_w && w != nullptr, w != nullptr, tid_scale,
                        0.f, 0.f, 0.f, 0.f);
   const int nblk = loss_blocks((long)B * H * W);
-  hipLaunchKernelGGL(pixgrad_fwd_kernel, dim3(nblk), dim3(LT), 0, stream, pred, target, w, c, gx, gy, partials);
+  launch_pixgrad_fwd(pred, target, w, c, gx, gy, partials, nblk, stream);
   UNETK_CHECK_LAUNCH();
   hipLaunchKernelGGL(pixgrad_finalize_kernel, dim3(1), dim3(LT), 0, stream, partials, nblk, c, res);
   UNETK_CHECK_LAUNCH();
@@ -476,7 +664,7 @@ int unetk_loss_pixgrad_fwd_static(const float* pred, const float* target, const 
   LossCfg c = make_cfg(B, H, W, pixel_mae, grad_method, pixel_use_w && w != nullptr, w != nullptr, tid_scale,
                        0.f, 0.f, 0.f, 0.f);
   // every partial the finalize kernel reads is written by this launch first: nothing to clear
-  hipLaunchKernelGGL(pixgrad_fwd_kernel, dim3(nblk), dim3(LT), 0, stream, pred, target, w, c, gx, gy, partials);
+  launch_pixgrad_fwd(pred, target, w, c, gx, gy, partials, nblk, stream);
   UNETK_CHECK_LAUNCH();
   hipLaunchKernelGGL(pixgrad_finalize_kernel, dim3(1), dim3(LT), 0, stream, partials, nblk, c, res);
   UNETK_CHECK_LAUNCH();
@@ -512,8 +700,12 @@ int unetk_loss_pixgrad_bwd(const float* pred, const float* target, const float* 
   UNETK_CHECK_ARG(pred && target && res && gout && dpred, "loss_pixgrad_bwd: null pointer");
   LossCfg c = make_cfg(B, H, W, pixel_mae, grad_method, 0, w != nullptr, 1.f, w_pixel, w_grad, 0.f, 0.f);
   const long npix = (long)B * H * W;
-  hipLaunchKernelGGL(pixgrad_bwd_kernel, dim3(cdiv(npix, 256)), dim3(256), 0, stream, pred, target, w, c, gx, gy,
-                     res, gout, use_grad, dpred, accumulate);
+  if (loss_vec4_ok(c, pred, target, w, gx, gy) && ((uintptr_t)dpred % 16) == 0)
+    hipLaunchKernelGGL(pixgrad_bwd_vec4_kernel, dim3(cdiv(npix / 4, 256)), dim3(256), 0, stream, pred, target, w, c, gx,
+                       gy, res, gout, use_grad, dpred, accumulate);
+  else
+    hipLaunchKernelGGL(pixgrad_bwd_kernel, dim3(cdiv(npix, 256)), dim3(256), 0, stream, pred, target, w, c, gx, gy,
+                       res, gout, use_grad, dpred, accumulate);
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }
