@@ -855,3 +855,21 @@ def test_fused_mlp_backward_matches_separate_launches(C, B, H, Wd):
     assert rel(dx, xr.grad + add.float().cpu()) < 1.5e-2 and rel(dg, gr.grad) < 1.5e-2 and rel(db, br.grad) < 1.5e-2
     with pytest.raises(ValueError):
         ops.swin_mlp_bwd(dy, hpre, p1t, p1t, x, mean, rstd, gamma, add, ops.DeferredSums())
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 4, 32, 48, 4), (3, 3, 20, 24, 4), (1, 5, 16, 16, 4), (2, 4, 18, 27, 3),
+                                   (2, 4, 16, 18, 4), (1, 1, 8, 8, 2)])
+def test_patchify_both_kernels(dt, shape):
+    """Patch tokens [c][ky][kx] as the strided patch-embedding conv reads them (swin_unet_model.py:452-453), the
+    padding channels zero: 4x4 patches of images whose width is a multiple of four take the 16-byte kernel, the
+    others the one-element one."""
+    from unet_amd import ops
+    B, Cin, H, W, ps = shape
+    x = torch.randn(B, Cin, H, W, generator=torch.Generator().manual_seed(5))
+    tok = ops.patchify(x.cuda(), ps, dt)
+    Hp, Wp, K = H // ps, W // ps, Cin * ps * ps
+    ref = x[:, :, :Hp * ps, :Wp * ps].reshape(B, Cin, Hp, ps, Wp, ps).permute(0, 2, 4, 1, 3, 5).reshape(B, Hp, Wp, K)
+    assert tok.shape[:3] == (B, Hp, Wp) and tok.shape[3] >= K
+    assert torch.equal(tok[..., :K].float().cpu(), ref.to(dt).float())
+    assert not tok[..., K:].any()

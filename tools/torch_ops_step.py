@@ -2,7 +2,7 @@
 """Which torch operators (and how many device copies / fills) one eager trainer step still launches beside the
 library's own kernels: the headline UNet step or the Swin step under torch.profiler, operators by call count.
 
-    python tools/torch_ops_step.py train [batch] [regex: also list every operator / kernel whose name matches]
+    python tools/torch_ops_step.py train|swin [batch] [regex: also list every operator / kernel whose name matches]
 """
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -35,7 +35,29 @@ if which == "train":
         loss.backward()
         opt.step()
 else:
-    raise SystemExit("only the UNet step is wired up here")
+    from oracle import swin_oracle
+    from unet_amd import ops
+    from unet_amd.losses import MultiLossFunction
+    from unet_amd.optim import FusedAdamW
+    from unet_amd.swin import SwinUNet
+    cfg = dict(swin_oracle.DEFAULT_CONFIG)
+    model = SwinUNet(cfg, compute_dtype=dt)
+    model.load_state_dict(W.fill_state_dict(swin_oracle.swin_template(cfg), seed=42))
+    model = model.to(dev).train()
+    x, y, w = (t.to(dev) for t in W.synthetic_batch(B, 4, 256, 256, seed=42))
+    crit = MultiLossFunction(bench.SWIN_LOSS_CFG).to(dev)
+    opt = FusedAdamW(model.parameters(), lr=1e-4, weight_decay=0.05, max_grad_norm=1.0)
+    params = list(model.parameters())
+
+    def step():
+        for p in params:
+            p.grad = None
+        out = model(x)
+        if out.shape[-2:] != y.shape[-2:]:
+            out = ops.interpolate_bilinear(out, y.shape[-2:])
+        loss, _ = crit(out, y, w)
+        loss.backward()
+        opt.step()
 
 for _ in range(3):
     step()

@@ -486,6 +486,41 @@ __global__ void patchify_kernel(const float* __restrict__ x, T* __restrict__ tok
   tok[idx] = from_f32<T>(v);
 }
 
+// The same for 4x4 patches (W % 4 == 0, ld % 4 == 0, 16-byte aligned images): one thread per (token, four consecutive
+// k) = one 16-byte read of a patch row and one 8- or 16-byte write; a wave writes the 64-wide tokens of four patches
+// as one run.
+template <typename T>
+__global__ void patchify4_kernel(const float* __restrict__ x, T* __restrict__ tok, int B, int Cin, int H, int W,
+                                 int Hp, int Wp, int ld) {
+  const int kq = ld / 4;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)B * Hp * Wp * kq) return;
+  const int k = (int)(idx % kq) * 4;
+  long p = idx / kq;
+  const long token = p;
+  const int xp = p % Wp;
+  p /= Wp;
+  const int yp = p % Hp;
+  const int b = p / Hp;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (k < Cin * 16) {
+    const int c = k >> 4, ky = (k >> 2) & 3;
+    v = *reinterpret_cast<const f32x4*>(x + (((long)b * Cin + c) * H + 4 * yp + ky) * W + 4 * xp);
+  }
+  T* d = tok + token * ld + k;
+  if constexpr (sizeof(T) == 2) {
+    union {
+      T h[4];
+      uint2 u;
+    } o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o.h[i] = from_f32<T>(v[i]);
+    *reinterpret_cast<uint2*>(d) = o.u;
+  } else {
+    *reinterpret_cast<f32x4*>(d) = v;
+  }
+}
+
 template <typename T>
 __global__ void unpatchify_kernel(const T* __restrict__ dtok, float* __restrict__ dx, int B, int Cin, int H, int W,
                                   int ps, int Hp, int Wp, int ld) {
@@ -1173,6 +1208,12 @@ int unetk_patchify(const float* x, void* tok, int B, int Cin, int H, int W, int 
   CHECK_DT("patchify", dtype);
   const int Hp = H / ps, Wp = W / ps;
   const long total = (long)B * Hp * Wp * ld;
+  if (ps == 4 && W % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)tok % 16) == 0) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(patchify4_kernel<T>, dim3(cdiv(total / 4, 256)), dim3(256), 0, stream, x,
+                                         (T*)tok, B, Cin, H, W, Hp, Wp, ld));
+    UNETK_CHECK_LAUNCH();
+    return UNETK_OK;
+  }
   DISPATCH_T(dtype, hipLaunchKernelGGL(patchify_kernel<T>, dim3(cdiv(total, 256)), dim3(256), 0, stream, x, (T*)tok,
                                        B, Cin, H, W, ps, Hp, Wp, ld));
   UNETK_CHECK_LAUNCH();
