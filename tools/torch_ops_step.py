@@ -15,6 +15,9 @@ dev = torch.device("cuda:0")
 dt = torch.bfloat16
 from oracle import weights as W          # synthetic weights and batch only (a bench-side helper, not the product path)
 import bench
+from unet_amd import _lib
+if os.environ.get("UNETK_AB_LIB"):      # A/B a kernel variant built to another file
+    _lib.LIB_PATH = os.path.abspath(os.environ["UNETK_AB_LIB"])
 
 if which == "train":
     from unet_amd import OptimizedUNet
