@@ -244,6 +244,14 @@ int unetk_upsample_concat_fwd(const void* low, int h, int w, int C1, const void*
                               void* out, int B, int H, int W, int dtype, unetk_stream_t stream);
 int unetk_upsample_bwd(const void* dout, int ldout, int H, int W, void* dlow, int B, int h, int w, int C1,
                        int dtype, unetk_stream_t stream);
+/* The last BatchNorm + ReLU + Dropout2d of a block and the exact 2x resize in front of the next decoder block
+ * (training.py:522-531 followed by :504-517) in one pass: out[b, 2h x 2w, 0:C1) = resize(relu(y*scale+shift)*keep),
+ * pixel stride ldo elements (C1 for a dense result, C1+C2 for the concat buffer); the activation itself is not
+ * stored (nothing else reads it).  keep: (B, C1) fp32 factors or NULL.  bfloat16, C1 a multiple of 32; the same
+ * bits as unetk_bn_act_fwd followed by unetk_upsample_concat_fwd. */
+int unetk_bn_act_upsample2x_supported(int h, int w, int C1, int dtype);
+int unetk_bn_act_upsample2x(const void* y, int B, int h, int w, int C1, const float* scale, const float* shift,
+                            const float* keep, void* out, int ldo, int dtype, unetk_stream_t stream);
 
 /* F.interpolate(outputs, size=labels.shape[-2:], mode='bilinear', align_corners=False) on the fp32
  * NCHW prediction before the loss (swin_unet_model.py:812-814): in (planes,h,w) -> out (planes,H,W),

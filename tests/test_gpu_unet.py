@@ -320,3 +320,55 @@ def test_backward_fusions_agree_with_the_separate_passes(monkeypatch):
     errs = sorted(rel(res[(True, True)][1][n], g) for n, g in base.items())
     print("fused-sums vs separate, relative L2 per parameter: median %.2e, worst %.2e" % (errs[len(errs) // 2], errs[-1]))
     assert errs[len(errs) // 2] < 1e-2 and errs[-1] < 5e-2, errs[-5:]
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_bn_relu_inside_the_upsampling_gives_the_same_bits(monkeypatch, masked):
+    """The last BatchNorm + ReLU + Dropout2d of the bottleneck and of decoder4..2 formed inside the 2x resize that is
+    its only reader (no stored activation) against the two separate passes: output and every gradient, bit for bit;
+    with all-ones factors and with live Dropout2d masks."""
+    from unet_amd import unet as U
+    m, sd, x, y = build("f48", torch.bfloat16)
+    m.train()
+    if masked:
+        g = torch.Generator().manual_seed(11)
+        B = x.shape[0]
+        m.dropout_masks_override = [(torch.rand(B, getattr(m, n)[3].out_channels, generator=g) > 0.3).float() / 0.7
+                                    for n in U.BLOCKS]
+    else:
+        m.dropout_masks_override = [None] * 9
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(U, "FUSE_BN_UPSAMPLE", fused)
+        m.load_state_dict(sd)
+        m.zero_grad()
+        out = m(x.cuda())
+        ((out - y.cuda()) ** 2).mean().backward()
+        res[fused] = (out.clone(), {n: p.grad.clone() for n, p in m.named_parameters()})
+    assert torch.equal(res[True][0], res[False][0])
+    assert all(torch.equal(res[True][1][n], g) for n, g in res[False][1].items())
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 8, 32), (1, 9, 13, 64), (3, 16, 24, 96), (2, 5, 3, 32), (1, 1, 1, 32)])
+@pytest.mark.parametrize("into_cat", [False, True])
+def test_bn_act_upsample_op(shape, into_cat):
+    """ops.bn_act_upsample against bn_act_fwd followed by the resize, dense and into a concat buffer whose other
+    half it must leave alone; ragged tiles, images smaller than a tile."""
+    from unet_amd import ops
+    B, h, w, C1 = shape
+    g = torch.Generator().manual_seed(3)
+    y = torch.randn(B, h, w, C1, generator=g).cuda().to(torch.bfloat16)
+    sc = (torch.rand(C1, generator=g) + 0.5).cuda()
+    sh = (torch.randn(C1, generator=g) * 0.3).cuda()
+    keep = ((torch.rand(B, C1, generator=g) > 0.2).float() / 0.8).cuda()
+    assert ops.bn_act_upsample_supported(y)
+    for kp in (None, keep):
+        a, _ = ops.bn_act_fwd(y, sc, sh, kp, relu=True)
+        if into_cat:
+            cat = torch.full((B, 2 * h, 2 * w, C1 + 16), 7.0, device="cuda", dtype=torch.bfloat16)
+            want = ops.upsample_into(a, cat.clone())
+            got = ops.bn_act_upsample(y, sc, sh, kp, cat=cat)
+        else:
+            want = ops.upsample(a, 2 * h, 2 * w)
+            got = ops.bn_act_upsample(y, sc, sh, kp)
+        assert torch.equal(got, want)

@@ -54,6 +54,12 @@ for hw, C in levels:
     cat = torch.empty(B, hw, hw, 3 * C, device="cuda", dtype=dt)
     res["upsample_into"] = (timeit(lambda: ops.upsample_into(low, cat)), (0.5 + 2) * S)
     res["upsample_bwd"] = (timeit(lambda: ops.upsample_bwd(dup, 2 * C, hw // 2, hw // 2)), 2.5 * S)
+    # the last BatchNorm + ReLU of the block below and its resize to this level: two passes / one
+    ylow = torch.randn(B, hw // 2, hw // 2, 2 * C, device="cuda").to(dt)
+    sc2, sh2 = torch.rand(2 * C, device="cuda") + 0.5, torch.randn(2 * C, device="cuda") * 0.3
+    res["bn+upsample 2 passes"] = (timeit(lambda: ops.upsample(ops.bn_act_fwd(ylow, sc2, sh2, None, relu=True)[0], hw, hw)), (0.5 + 0.5 + 0.5 + 2) * S)
+    if ops.bn_act_upsample_supported(ylow):
+        res["bn+upsample fused"] = (timeit(lambda: ops.bn_act_upsample(ylow, sc2, sh2, None)), (0.5 + 2) * S)
     line = f"{hw:4d}^2 C={C:4d} S={S*1e3:6.0f} MB |"
     for k, (t, gb) in res.items():
         line += f" {k} {t*1e3:6.0f} us {gb/t:5.2f} TB/s |"

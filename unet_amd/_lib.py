@@ -84,6 +84,8 @@ _SIGNATURES = {
     "unetk_pool_bwd": (I, [P, P, P, P, I, P, I, I, I, I, I, P]),
     "unetk_upsample_concat_fwd": (I, [P, I, I, I, P, I, I, P, I, I, I, I, P]),
     "unetk_upsample_bwd": (I, [P, I, I, I, P, I, I, I, I, I, P]),
+    "unetk_bn_act_upsample2x_supported": (I, [I, I, I, I]),
+    "unetk_bn_act_upsample2x": (I, [P, I, I, I, I, P, P, P, P, I, I, P]),
     "unetk_resize_planes_f32": (I, [P, P, L, I, I, I, I, I, P]),
     "unetk_head1x1_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, P]),
     "unetk_head1x1_bwd": (I, [P, I, P, P, P, P, P, I, I, I, I, I, I, P, I, P]),

@@ -948,6 +948,88 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tile_kernel(const bf16* __
   store16(dlow + (((long)b * h + i) * w + j) * C1 + slab * 32 + cg * 8, o);
 }
 
+// BatchNorm + ReLU (+ Dropout2d factors) of a block's last conv output y and the exact 2x up-sampling of the result
+// in ONE pass (bfloat16, C1 a multiple of 32): the activation a = relu(y*scale+shift)*keep is consumed by nothing but
+// the up-sampling in front of the next decoder block, so it is formed on the way into LDS (rounded to bf16 as the
+// separate pass would store it) and never written.  A workgroup owns an 8 x 8 tile of y times 32 channels, stages
+// its 10 x 10 neighbourhood (border pixels replicated, as the clamped source indices of the resize read them) and
+// every thread writes the 2 x 2 output pixels of its y pixel with the index / weight arithmetic of
+// upsample2x_concat_kernel.  XCD x walks a contiguous eighth of the (tile, channel slab) list, slabs fastest.
+template <int NSL>      // 32-channel slabs a workgroup takes side by side: runs of 64 * NSL bytes per pixel, in and out
+__global__ __launch_bounds__(256) void bn_act_upsample2x_tile_kernel(const bf16* __restrict__ y, int h, int w, int C1,
+                                                                      const float* __restrict__ scale,
+                                                                      const float* __restrict__ shift,
+                                                                      const float* __restrict__ keep,
+                                                                      bf16* __restrict__ out, int ldo, int tiles_x,
+                                                                      int tiles_y, long nitems) {
+  using T = bf16;
+  constexpr int TP = 8, HP = TP + 2;
+  constexpr int VPP = 4 * NSL, PB = 16 * VPP;            // 16-byte vectors / bytes of a patch pixel
+  __shared__ __attribute__((aligned(16))) char patch[HP * HP * PB];
+  const long item = xcd_contiguous_block();
+  if (item >= nitems) return;
+  const int nslab = C1 / (32 * NSL);
+  const int slab = (int)(item % nslab);
+  long t = item / nslab;
+  const int tx = (int)(t % tiles_x);
+  t /= tiles_x;
+  const int ty = (int)(t % tiles_y);
+  const int b = (int)(t / tiles_y);
+  const int i0 = ty * TP, j0 = tx * TP;
+  const int cbase = slab * 32 * NSL;
+  const T* base = y + (long)b * h * w * C1 + cbase;
+#pragma unroll
+  for (int sidx = threadIdx.x; sidx < HP * HP * VPP; sidx += 256) {
+    const int px = sidx / VPP, sl = sidx - px * VPP;
+    const int py = px / HP, pxx = px - py * HP;
+    int Y = i0 - 1 + py, X = j0 - 1 + pxx;
+    Y = Y < 0 ? 0 : (Y > h - 1 ? h - 1 : Y);
+    X = X < 0 ? 0 : (X > w - 1 ? w - 1 : X);
+    const Vec16<T> v = load16(base + ((long)Y * w + X) * C1 + sl * 8);
+    const int c0 = cbase + sl * 8;
+    // (the per-channel factors as 16-byte loads: c0 is a multiple of eight floats)
+    const f32x4 sc0 = *reinterpret_cast<const f32x4*>(scale + c0), sc1 = *reinterpret_cast<const f32x4*>(scale + c0 + 4);
+    const f32x4 sh0 = *reinterpret_cast<const f32x4*>(shift + c0), sh1 = *reinterpret_cast<const f32x4*>(shift + c0 + 4);
+    f32x4 k0 = {1.f, 1.f, 1.f, 1.f}, k1 = k0;
+    if (keep) {
+      k0 = *reinterpret_cast<const f32x4*>(keep + (long)b * C1 + c0);
+      k1 = *reinterpret_cast<const f32x4*>(keep + (long)b * C1 + c0 + 4);
+    }
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float z = fmaf(to_f32(v.v[e]), e < 4 ? sc0[e & 3] : sc1[e & 3], e < 4 ? sh0[e & 3] : sh1[e & 3]);
+      z = fmaxf(z, 0.f);
+      o.v[e] = from_f32<T>(z * (e < 4 ? k0[e & 3] : k1[e & 3]));
+    }
+    *reinterpret_cast<Vec16<T>*>(patch + px * PB + sl * 16) = o;
+  }
+  __syncthreads();
+  const int H = 2 * h, W = 2 * w;
+  for (int idx = threadIdx.x; idx < TP * TP * VPP; idx += 256) {
+    const int pix = idx / VPP, vq = idx - pix * VPP;
+    const int i = i0 + (pix >> 3), j = j0 + (pix & 7);
+    if (i >= h || j >= w) continue;
+    T* o = out + (((long)b * H + 2 * i) * W + 2 * j) * ldo + cbase + vq * 8;
+    auto at = [&](int yy, int xx) {
+      return *reinterpret_cast<const Vec16<T>*>(patch + ((yy - (i0 - 1)) * HP + (xx - (j0 - 1))) * PB + vq * 16);
+    };
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      int y0, y1;
+      float ly;
+      src_index(0.5f, 2 * i + a, h, y0, y1, ly);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        int x0, x1;
+        float lx;
+        src_index(0.5f, 2 * j + c, w, x0, x1, lx);
+        store16(o + ((long)a * W + c) * ldo, bilerp(at(y0, x0), at(y0, x1), at(y1, x0), at(y1, x1), ly, lx));
+      }
+    }
+  }
+}
+
 // dlow[b,i,j,:] = sum over output pixels (y,x) that read (i,j) of wy*wx*dout[b,y,x,:] (gather form)
 template <typename T>
 __global__ void upsample_bwd_kernel(const T* __restrict__ dout, int ldout, int H, int W, T* __restrict__ dlow,
@@ -1414,6 +1496,44 @@ int unetk_upsample_concat_fwd(const void* low, int h, int w, int C1, const void*
                                          stream, (const T*)low, h, w, C1, (const T*)skip, ldskip, C2, (T*)out,
                                          B, H, W, sy, sx));
   }
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_bn_act_upsample2x_supported(int h, int w, int C1, int dtype) {
+  return dtype == UNETK_BF16 && C1 % 32 == 0 && h >= 1 && w >= 1 && std::getenv("UNETK_NO_BN_UPSAMPLE") == nullptr;
+}
+
+int unetk_bn_act_upsample2x(const void* y, int B, int h, int w, int C1, const float* scale, const float* shift,
+                            const float* keep, void* out, int ldo, int dtype, hipStream_t stream) {
+  UNETK_CHECK_ARG(y && scale && shift && out, "bn_act_upsample2x: null pointer");
+  UNETK_CHECK_ARG(unetk_bn_act_upsample2x_supported(h, w, C1, dtype) && B > 0,
+                  "bn_act_upsample2x: bfloat16 and a multiple of 32 channels (got dtype %d, %d channels)", dtype, C1);
+  UNETK_CHECK_ARG(ldo >= C1 && ldo % 8 == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)out % 16) == 0,
+                  "bn_act_upsample2x: output stride %d (>= C1, multiple of 8, 16-byte aligned bases)", ldo);
+  UNETK_CHECK_ARG(((uintptr_t)scale % 16) == 0 && ((uintptr_t)shift % 16) == 0 && ((uintptr_t)keep % 16) == 0,
+                  "bn_act_upsample2x: scale, shift and keep must be 16-byte aligned");
+  UNETK_CHECK_ARG((long)B * 4 * h * w * ldo < (1L << 40), "bn_act_upsample2x: tensor too large");
+  const int tiles_x = cdiv(w, 8), tiles_y = cdiv(h, 8);
+  // slabs a workgroup takes side by side: two where the channels allow it, else three (measured at batch 64: 128-byte
+  // runs per pixel beat 64-byte ones by 10-25 %, and 192-byte ones by 5-20 %; a 96-channel tensor gains 12 % from
+  // three over one)
+  const int nb = C1 / 32;
+  int nsl = nb % 2 == 0 ? 2 : (nb % 3 == 0 ? 3 : 1);
+  if (const char* ev = std::getenv("UNETK_BN_UPSAMPLE_SLABS")) {
+    const int v = atoi(ev);
+    if ((v == 1 || v == 2 || v == 3) && nb % v == 0) nsl = v;
+  }
+  const long nitems = (long)B * tiles_x * tiles_y * (nb / nsl);
+  UNETK_CHECK_ARG(nitems < (1L << 30), "bn_act_upsample2x: too many tiles");
+  const dim3 grid((unsigned)(8 * cdiv(nitems, 8)));
+#define BN_UP(N)                                                                                                   \
+  hipLaunchKernelGGL(bn_act_upsample2x_tile_kernel<N>, grid, dim3(256), 0, stream, (const bf16*)y, h, w, C1, scale, \
+                     shift, keep, (bf16*)out, ldo, tiles_x, tiles_y, nitems)
+  if (nsl == 3) BN_UP(3);
+  else if (nsl == 2) BN_UP(2);
+  else BN_UP(1);
+#undef BN_UP
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }

@@ -580,6 +580,28 @@ def upsample(low, H, W):
     return out
 
 
+def bn_act_upsample_supported(y, *factors):
+    """factors: the scale / shift / keep tensors, when known (their 16-byte alignment is part of the answer)."""
+    B, h, w, C1 = y.shape
+    return bool(_lib.load().unetk_bn_act_upsample2x_supported(h, w, C1, dtype_code(y.dtype))) and \
+        all(f is None or f.data_ptr() % 16 == 0 for f in factors)
+
+
+def bn_act_upsample(y, scale, shift, keep, cat=None):
+    """resize2x(relu(y*scale+shift)*keep) without storing the activation: into channels [0,C1) of the concat buffer
+    ``cat`` (B,2h,2w,C1+C2), or as a dense (B,2h,2w,C1) tensor.  The same bits as bn_act_fwd + upsample(_into)."""
+    B, h, w, C1 = y.shape
+    assert y.is_contiguous()
+    if cat is None:
+        out = torch.empty((B, 2 * h, 2 * w, C1), dtype=y.dtype, device=y.device)
+    else:
+        assert cat.is_contiguous() and cat.shape[:3] == (B, 2 * h, 2 * w) and cat.shape[3] > C1
+        out = cat
+    call("unetk_bn_act_upsample2x", ptr(y), B, h, w, C1, ptr(scale), ptr(shift), ptr(keep), ptr(out), out.shape[3],
+         dtype_code(y.dtype), stream())
+    return out
+
+
 def upsample_bwd(dcat, C1, h, w):
     """Gradient of the resized channels [0,C1) of dcat (B,H,W,>=C1; may be a channel slice) -> (B,h,w,C1)."""
     B, H, W, _ = dcat.shape

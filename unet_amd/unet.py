@@ -115,6 +115,9 @@ FUSE_BN_SUMS = os.environ.get("UNETK_FUSE_BN_SUMS", "1") != "0"
 # the gradient just written still in the last-level cache, than by a conv epilogue that has to fetch y again
 BN_SUMS_MAX_BYTES = int(os.environ.get("UNETK_BN_SUMS_MAX_BYTES", str(64 << 20)))
 FUSE_POOL_BWD = os.environ.get("UNETK_FUSE_POOL_BWD", "1") != "0"
+# the last BatchNorm + ReLU + Dropout2d of the bottleneck / a decoder block formed inside the 2x up-sampling that is its
+# only reader, instead of stored by a pass of its own (0: the separate pass, for A/B timing; same bits either way)
+FUSE_BN_UPSAMPLE = os.environ.get("UNETK_FUSE_BN_UPSAMPLE", "1") != "0"
 _SIDE_STREAMS = {}
 
 
@@ -236,10 +239,12 @@ class _UNetTrainFn(torch.autograd.Function):
         h = ops.nchw_to_nhwc(x.detach(), dt)
         saved["x"] = h
 
-        def block(name, t, keep, pool, cat_c1=0):
+        def block(name, t, keep, pool, cat_c1=0, up_to=None):
             """conv-BN-ReLU twice (+Dropout2d mask, + 2x2 max-pool for encoder blocks).  An encoder
             block writes its output straight into the skip half of its decoder's concat buffer
-            (channels [cat_c1:]) and keeps the pooling argmax map for the backward."""
+            (channels [cat_c1:]) and keeps the pooling argmax map for the backward.  up_to: the (H, W) the
+            block's output is resized to by its only reader; where the fused pass applies the block returns
+            ("deferred", y, scale, shift, keep) instead of the activation."""
             seq = getattr(model, name)
             units = []
             pooled = argmax = cat = None
@@ -265,6 +270,9 @@ class _UNetTrainFn(torch.autograd.Function):
                     cat = torch.empty((Bn, H, W, cat_c1 + C), dtype=y.dtype, device=y.device)
                     a, pooled, argmax = ops.bn_act_fwd(y, sc, sh, keep, relu=True, pool=True,
                                                        out=cat[..., cat_c1:], want_argmax=True)
+                elif (last and FUSE_BN_UPSAMPLE and up_to is not None and tuple(up_to) == (2 * H, 2 * W)
+                      and ops.bn_act_upsample_supported(y, sc, sh, keep)):
+                    a = ("deferred", y, sc, sh, keep)
                 else:
                     a, _ = ops.bn_act_fwd(y, sc, sh, keep if last else None, relu=True)
                 units.append((t, y, mean, invstd, sc, sh))
@@ -279,16 +287,24 @@ class _UNetTrainFn(torch.autograd.Function):
         _, p2, cat2 = block("encoder2", p1, masks[1], True, up_channels("decoder2", "encoder2"))
         _, p3, cat3 = block("encoder3", p2, masks[2], True, up_channels("decoder3", "encoder3"))
         _, p4, cat4 = block("encoder4", p3, masks[3], True, up_channels("decoder4", "encoder4"))
-        d, _, _ = block("bottleneck", p4, masks[4], False)
-        for i, (name, cat) in enumerate((("decoder4", cat4), ("decoder3", cat3), ("decoder2", cat2),
-                                         ("decoder1", cat1))):
-            low_hw = d.shape[1:3]
-            saved[name + ".low"] = (low_hw, d.shape[3])
-            if _reads_pair(d.shape[3]):
-                joined = (ops.upsample(d, cat.shape[1], cat.shape[2]), cat)
+        cats = (("decoder4", cat4), ("decoder3", cat3), ("decoder2", cat2), ("decoder1", cat1))
+        d, _, _ = block("bottleneck", p4, masks[4], False, up_to=cat4.shape[1:3])
+        for i, (name, cat) in enumerate(cats):
+            if isinstance(d, tuple):        # BatchNorm + ReLU + Dropout2d ride on the resize
+                _, y_low, sc_low, sh_low, keep_low = d
+                saved[name + ".low"] = (y_low.shape[1:3], y_low.shape[3])
+                if _reads_pair(y_low.shape[3]):
+                    joined = (ops.bn_act_upsample(y_low, sc_low, sh_low, keep_low), cat)
+                else:
+                    joined = ops.bn_act_upsample(y_low, sc_low, sh_low, keep_low, cat=cat)
             else:
-                joined = ops.upsample_into(d, cat)
-            d, _, _ = block(name, joined, masks[5 + i], False)
+                saved[name + ".low"] = (d.shape[1:3], d.shape[3])
+                if _reads_pair(d.shape[3]):
+                    joined = (ops.upsample(d, cat.shape[1], cat.shape[2]), cat)
+                else:
+                    joined = ops.upsample_into(d, cat)
+            d, _, _ = block(name, joined, masks[5 + i], False,
+                            up_to=cats[i + 1][1].shape[1:3] if i + 1 < len(cats) else None)
         saved["head_in"] = d
         out = ops.head1x1_fwd(d, model.conv.weight, model.conv.bias)
         if tracked:
