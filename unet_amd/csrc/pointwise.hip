@@ -279,7 +279,15 @@ __global__ __launch_bounds__(256) void bn_act_stream_kernel(const T* __restrict_
 #pragma unroll
     for (int e = 0; e < E; ++e) kp[e] = keep ? keep[(size_t)b * C + c0 + e] : 1.f;
     unsigned p = seg + pl;
-    for (; p + lanes < seg_end; p += 2 * lanes) {     // two pixels in flight
+    for (; p + 3 * lanes < seg_end; p += 4 * lanes) {     // four pixels in flight
+      const Vec16<T> v0 = load16(y + (size_t)p * ldy + c0), v1 = load16(y + (size_t)(p + lanes) * ldy + c0);
+      const Vec16<T> v2 = load16(y + (size_t)(p + 2 * lanes) * ldy + c0), v3 = load16(y + (size_t)(p + 3 * lanes) * ldy + c0);
+      one(p, v0, kp);
+      one(p + lanes, v1, kp);
+      one(p + 2 * lanes, v2, kp);
+      one(p + 3 * lanes, v3, kp);
+    }
+    for (; p + lanes < seg_end; p += 2 * lanes) {
       const Vec16<T> v0 = load16(y + (size_t)p * ldy + c0), v1 = load16(y + (size_t)(p + lanes) * ldy + c0);
       one(p, v0, kp);
       one(p + lanes, v1, kp);
@@ -451,15 +459,25 @@ __global__ __launch_bounds__(RED_THREADS) void channel_reduce_kernel(RedArgs a) 
         seg = seg_end;
       }
     } else {
-      for (long p = pbeg + pl; p < pend; p += lanes) {
-        Vec16<T> xv = load16(x + p * a.ldx + c0);
-        const float d = reinterpret_cast<const float*>(a.g)[p];
+      const float* dp = reinterpret_cast<const float*>(a.g);
+      auto acc1 = [&](const Vec16<T>& xv, float d) {
 #pragma unroll
         for (int e = 0; e < E; ++e) {
           s0[e] += d * to_f32(xv.v[e]);
           s1[e] += d;
         }
+      };
+      long p = pbeg + pl;
+      for (; p + 3 * lanes < pend; p += 4 * lanes) {      // four pixels in flight, added in pixel order
+        const Vec16<T> x0 = load16(x + p * a.ldx + c0), x1 = load16(x + (p + lanes) * a.ldx + c0);
+        const Vec16<T> x2 = load16(x + (p + 2 * lanes) * a.ldx + c0), x3 = load16(x + (p + 3 * lanes) * a.ldx + c0);
+        const float d0 = dp[p], d1 = dp[p + lanes], d2 = dp[p + 2 * lanes], d3 = dp[p + 3 * lanes];
+        acc1(x0, d0);
+        acc1(x1, d1);
+        acc1(x2, d2);
+        acc1(x3, d3);
       }
+      for (; p < pend; p += lanes) acc1(load16(x + p * a.ldx + c0), dp[p]);
     }
   }
 #pragma unroll
@@ -895,13 +913,24 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tile_kernel(const bf16* __
   const int i0 = ty * TP, j0 = tx * TP;
   const int Y0 = 2 * i0 - 1, X0 = 2 * j0 - 1;
   const T* base = dout + (long)b * H * W * ldout + slab * 32;
-  for (int sidx = threadIdx.x; sidx < HP * HP * 4; sidx += 256) {
-    const int px = sidx >> 2, sl = sidx & 3;
-    const int py = px / HP, pxx = px - py * HP;
-    const int Y = Y0 + py, X = X0 + pxx;
-    Vec16<T> v = zero16<T>();
-    if ((unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W) v = load16(base + ((long)Y * W + X) * ldout + sl * 8);
-    *reinterpret_cast<Vec16<T>*>(patch + px * 64 + sl * 16) = v;
+  {   // all of a thread's loads in flight before the first LDS store
+    constexpr int NLD = (HP * HP * 4 + 255) / 256;
+    Vec16<T> stage[NLD];
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+      const int sidx = threadIdx.x + it * 256;
+      const int px = sidx >> 2, sl = sidx & 3;
+      const int py = px / HP, pxx = px - py * HP;
+      const int Y = Y0 + py, X = X0 + pxx;
+      stage[it] = zero16<T>();
+      if (sidx < HP * HP * 4 && (unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W)
+        stage[it] = load16(base + ((long)Y * W + X) * ldout + sl * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+      const int sidx = threadIdx.x + it * 256;
+      if (sidx < HP * HP * 4) *reinterpret_cast<Vec16<T>*>(patch + (sidx >> 2) * 64 + (sidx & 3) * 16) = stage[it];
+    }
   }
   __syncthreads();
   const int cg = threadIdx.x & 3, pix = threadIdx.x >> 2;
