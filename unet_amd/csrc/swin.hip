@@ -225,24 +225,39 @@ __global__ __launch_bounds__(256) void layernorm_bwd_group_kernel(const T* __res
   for (int k = 0; k < V; ++k)
 #pragma unroll
     for (int e = 0; e < E; ++e) ag[k][e] = ab[k][e] = 0.f;
+  // gamma of this thread's channels, kept in registers
+  float gm[V][E];
+#pragma unroll
+  for (int k = 0; k < V; ++k)
+#pragma unroll
+    for (int e = 0; e < E; ++e) gm[k][e] = (k * G + gl) < CG ? gamma[(k * G + gl) * E + e] : 0.f;
   for (long t0 = pbeg; t0 < pend; t0 += TPW) {        // (uniform trip count: the shuffles need whole waves)
     const long tok = t0 + tg;
     const bool live = tok < pend;
     const long tk = live ? tok : pbeg;
     const float mu = mean[tk], rs = rstd[tk];
-    Vec16<T> dv[V], xv[V];
+    Vec16<T> dv[V], xv[V], av[V];
     float s1 = 0.f, s2 = 0.f;
+    // every load of the token first (the residual gradient too: it does not wait for the sums)
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      const int cg = k * G + gl;
+      av[k] = zero16<T>();
+      if (cg < CG) {
+        dv[k] = load16(dy + tk * C + cg * E);
+        xv[k] = load16(x + tk * C + cg * E);
+        if (add != nullptr) av[k] = load16(add + tk * C + cg * E);
+      }
+    }
 #pragma unroll
     for (int k = 0; k < V; ++k) {
       const int cg = k * G + gl;
       if (cg < CG) {
-        dv[k] = load16(dy + tk * C + cg * E);
-        xv[k] = load16(x + tk * C + cg * E);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
           const float d = live ? to_f32(dv[k].v[e]) : 0.f;
           const float xh = (to_f32(xv[k].v[e]) - mu) * rs;
-          const float g = d * gamma[cg * E + e];
+          const float g = d * gm[k][e];
           s1 += g;
           s2 += g * xh;
           ag[k][e] += d * xh;
@@ -258,14 +273,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_group_kernel(const T* __res
       for (int k = 0; k < V; ++k) {
         const int cg = k * G + gl;
         if (cg < CG) {
-          Vec16<T> av = zero16<T>();
-          if (add != nullptr) av = load16(add + tok * C + cg * E);
           Vec16<T> o;
 #pragma unroll
           for (int e = 0; e < E; ++e) {
-            const float g = to_f32(dv[k].v[e]) * gamma[cg * E + e];
+            const float g = to_f32(dv[k].v[e]) * gm[k][e];
             const float xh = (to_f32(xv[k].v[e]) - mu) * rs;
-            o.v[e] = from_f32<T>(rs * (g - s1 - xh * s2) + (add ? to_f32(av.v[e]) : 0.f));
+            o.v[e] = from_f32<T>(rs * (g - s1 - xh * s2) + (add ? to_f32(av[k].v[e]) : 0.f));
           }
           store16(dx + tok * C + cg * E, o);
           if (dxs != nullptr) {
