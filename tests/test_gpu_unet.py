@@ -372,3 +372,11 @@ def test_bn_act_upsample_op(shape, into_cat):
             want = ops.upsample(a, 2 * h, 2 * w)
             got = ops.bn_act_upsample(y, sc, sh, kp)
         assert torch.equal(got, want)
+        # the plain resize takes the tiled kernel too: against the one-thread-per-pixel kernel
+        import os
+        os.environ["UNETK_UPSAMPLE_NO_TILE"] = "1"
+        try:
+            old = ops.upsample_into(a, cat.clone()) if into_cat else ops.upsample(a, 2 * h, 2 * w)
+        finally:
+            del os.environ["UNETK_UPSAMPLE_NO_TILE"]
+        assert torch.equal(old, want)

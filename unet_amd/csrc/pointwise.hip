@@ -984,7 +984,8 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tile_kernel(const bf16* __
 // its 10 x 10 neighbourhood (border pixels replicated, as the clamped source indices of the resize read them) and
 // every thread writes the 2 x 2 output pixels of its y pixel with the index / weight arithmetic of
 // upsample2x_concat_kernel.  XCD x walks a contiguous eighth of the (tile, channel slab) list, slabs fastest.
-template <int NSL>      // 32-channel slabs a workgroup takes side by side: runs of 64 * NSL bytes per pixel, in and out
+// BN = false: the plain resize of a stored activation (y is that activation; scale, shift and keep are not read).
+template <int NSL, bool BN = true>   // NSL 32-channel slabs a workgroup takes side by side: runs of 64 * NSL bytes per pixel
 __global__ __launch_bounds__(256) void bn_act_upsample2x_tile_kernel(const bf16* __restrict__ y, int h, int w, int C1,
                                                                       const float* __restrict__ scale,
                                                                       const float* __restrict__ shift,
@@ -1015,6 +1016,10 @@ __global__ __launch_bounds__(256) void bn_act_upsample2x_tile_kernel(const bf16*
     Y = Y < 0 ? 0 : (Y > h - 1 ? h - 1 : Y);
     X = X < 0 ? 0 : (X > w - 1 ? w - 1 : X);
     const Vec16<T> v = load16(base + ((long)Y * w + X) * C1 + sl * 8);
+    if constexpr (!BN) {
+      *reinterpret_cast<Vec16<T>*>(patch + px * PB + sl * 16) = v;
+      continue;
+    }
     const int c0 = cbase + sl * 8;
     // (the per-channel factors as 16-byte loads: c0 is a multiple of eight floats)
     const f32x4 sc0 = *reinterpret_cast<const f32x4*>(scale + c0), sc1 = *reinterpret_cast<const f32x4*>(scale + c0 + 4);
@@ -1301,6 +1306,33 @@ inline int reduce_blocks(long npix) {
 #define CHECK_VEC(name, dtype, C) \
   UNETK_CHECK_ARG((C) % ((dtype) == UNETK_BF16 ? 8 : 4) == 0, name ": channel count %d not a multiple of %d", (C), ((dtype) == UNETK_BF16 ? 8 : 4))
 
+// launch of the tiled 2x resize (with or without the BatchNorm + ReLU in front of it)
+template <bool BN>
+static int launch_upsample2x_tile(const void* y, int B, int h, int w, int C1, const float* scale, const float* shift,
+                                  const float* keep, void* out, int ldo, hipStream_t stream) {
+  const int tiles_x = cdiv(w, 8), tiles_y = cdiv(h, 8);
+  // slabs a workgroup takes side by side: two where the channels allow it, else three (measured at batch 64: 128-byte
+  // runs per pixel beat 64-byte ones by 10-25 %, and 192-byte ones by 5-20 %; a 96-channel tensor gains 12 % from
+  // three over one)
+  const int nb = C1 / 32;
+  int nsl = nb % 2 == 0 ? 2 : (nb % 3 == 0 ? 3 : 1);
+  if (const char* ev = std::getenv("UNETK_BN_UPSAMPLE_SLABS")) {
+    const int v = atoi(ev);
+    if ((v == 1 || v == 2 || v == 3) && nb % v == 0) nsl = v;
+  }
+  const long nitems = (long)B * tiles_x * tiles_y * (nb / nsl);
+  UNETK_CHECK_ARG(nitems < (1L << 30), "upsample2x (tiled): too many tiles");
+  const dim3 grid((unsigned)(8 * cdiv(nitems, 8)));
+#define BN_UP(N)                                                                                                      \
+  hipLaunchKernelGGL((bn_act_upsample2x_tile_kernel<N, BN>), grid, dim3(256), 0, stream, (const bf16*)y, h, w, C1, scale, \
+                     shift, keep, (bf16*)out, ldo, tiles_x, tiles_y, nitems)
+  if (nsl == 3) BN_UP(3);
+  else if (nsl == 2) BN_UP(2);
+  else BN_UP(1);
+#undef BN_UP
+  return UNETK_OK;
+}
+
 extern "C" {
 
 int unetk_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int ld, int dtype,
@@ -1516,6 +1548,14 @@ int unetk_upsample_concat_fwd(const void* low, int h, int w, int C1, const void*
   const float sy = (float)h / (float)H, sx = (float)w / (float)W;
   const long total = (long)B * H * W * ((skip ? C1 + C2 : C1) / E);
   UNETK_CHECK_ARG(total < (1L << 31), "upsample_concat_fwd: tensor too large");
+  if (H == 2 * h && W == 2 * w && skip == nullptr && dtype == UNETK_BF16 && C1 % 32 == 0 && (C1 + C2) % 8 == 0 &&
+      ((uintptr_t)low % 16) == 0 && ((uintptr_t)out % 16) == 0 && std::getenv("UNETK_UPSAMPLE_NO_TILE") == nullptr) {
+    // the LDS-tiled form (each low-resolution pixel fetched once per workgroup instead of by nine threads)
+    const int rc = launch_upsample2x_tile<false>(low, B, h, w, C1, nullptr, nullptr, nullptr, out, C1 + C2, stream);
+    if (rc != UNETK_OK) return rc;
+    UNETK_CHECK_LAUNCH();
+    return UNETK_OK;
+  }
   if (H == 2 * h && W == 2 * w) {
     const long quads = total / 4;
     DISPATCH_T(dtype, hipLaunchKernelGGL(upsample2x_concat_kernel<T>, dim3(cdiv(quads, 256)), dim3(256), 0,
@@ -1543,26 +1583,8 @@ int unetk_bn_act_upsample2x(const void* y, int B, int h, int w, int C1, const fl
   UNETK_CHECK_ARG(((uintptr_t)scale % 16) == 0 && ((uintptr_t)shift % 16) == 0 && ((uintptr_t)keep % 16) == 0,
                   "bn_act_upsample2x: scale, shift and keep must be 16-byte aligned");
   UNETK_CHECK_ARG((long)B * 4 * h * w * ldo < (1L << 40), "bn_act_upsample2x: tensor too large");
-  const int tiles_x = cdiv(w, 8), tiles_y = cdiv(h, 8);
-  // slabs a workgroup takes side by side: two where the channels allow it, else three (measured at batch 64: 128-byte
-  // runs per pixel beat 64-byte ones by 10-25 %, and 192-byte ones by 5-20 %; a 96-channel tensor gains 12 % from
-  // three over one)
-  const int nb = C1 / 32;
-  int nsl = nb % 2 == 0 ? 2 : (nb % 3 == 0 ? 3 : 1);
-  if (const char* ev = std::getenv("UNETK_BN_UPSAMPLE_SLABS")) {
-    const int v = atoi(ev);
-    if ((v == 1 || v == 2 || v == 3) && nb % v == 0) nsl = v;
-  }
-  const long nitems = (long)B * tiles_x * tiles_y * (nb / nsl);
-  UNETK_CHECK_ARG(nitems < (1L << 30), "bn_act_upsample2x: too many tiles");
-  const dim3 grid((unsigned)(8 * cdiv(nitems, 8)));
-#define BN_UP(N)                                                                                                   \
-  hipLaunchKernelGGL(bn_act_upsample2x_tile_kernel<N>, grid, dim3(256), 0, stream, (const bf16*)y, h, w, C1, scale, \
-                     shift, keep, (bf16*)out, ldo, tiles_x, tiles_y, nitems)
-  if (nsl == 3) BN_UP(3);
-  else if (nsl == 2) BN_UP(2);
-  else BN_UP(1);
-#undef BN_UP
+  const int rc = launch_upsample2x_tile<true>(y, B, h, w, C1, scale, shift, keep, out, ldo, stream);
+  if (rc != UNETK_OK) return rc;
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }
